@@ -1,0 +1,216 @@
+/*
+ * rcflow.h -- C ABI of librcflow.so: MI355X (gfx950) dense Farneback optical flow and
+ * the per-pixel rip-current analysis that consumes it.
+ *
+ * This is the drop-in boundary for the one hot path of borgor/ripcurrents (SURVEY.md
+ * section 8b).  Every entry point names the reference interface it replaces; paths are
+ * relative to /root/reference/RipCurrents_main.  Plain pointers and sizes only; image
+ * arguments are (pointer, byte step) pairs laid out like cv::Mat (interleaved channels).
+ *
+ * Conventions
+ *  - returns RC_OK (0) or a negative RC_E* code; nothing throws across the ABI;
+ *  - the caller owns every buffer; the context owns its device workspaces;
+ *  - a context is bound to one GPU; `stream` selects one of its independent stream
+ *    slots (own HIP stream, workspaces and analysis state).  Calls on one slot are
+ *    ordered; distinct slots may be driven from distinct host threads;
+ *  - *_dev entry points take DEVICE pointers, enqueue on the slot's HIP stream and
+ *    return without waiting (rcflow_sync waits); the host-pointer forms copy in,
+ *    compute, copy out and return when the result is in the caller's buffer;
+ *  - there is no CPU fallback: without a usable HIP device rcflow_create fails.
+ */
+#ifndef RCFLOW_H
+#define RCFLOW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCFLOW_ABI_VERSION 1
+
+typedef struct rc_ctx rc_ctx;
+
+enum {
+    RC_OK = 0,
+    RC_EINVAL = -1,   /* bad argument (what cv::Exception / CV_Assert is in the reference) */
+    RC_ENOMEM = -2,   /* device or host allocation failed */
+    RC_EHIP = -3,     /* a HIP runtime call failed; rcflow_last_error() has the text */
+    RC_ENODEV = -4,   /* no usable gfx950 device */
+    RC_ESIZE = -5,    /* frame larger than the context was created for */
+    RC_ESTATE = -6,   /* call order violated (e.g. analysis before any flow) */
+    RC_ECOMM = -7     /* collective layer not initialised / failed */
+};
+
+/* cv::OPTFLOW_FARNEBACK_GAUSSIAN; cv::OPTFLOW_USE_INITIAL_FLOW (4) is rejected with
+ * RC_EINVAL: no reference call site uses it. */
+#define RC_FARNEBACK_GAUSSIAN 256
+
+/* ripcurrents.hpp:7-9 */
+#define RC_HIST_BINS 50
+#define RC_HIST_DIRECTIONS 36
+#define RC_HIST_RESOLUTION 20
+/* hist[50] | hist2d[36*50] | histsum | histsum2d[36]: the all-reduce payload */
+#define RC_HIST_WORDS (RC_HIST_BINS + RC_HIST_DIRECTIONS * RC_HIST_BINS + 1 + RC_HIST_DIRECTIONS)
+
+/* Parameters of cv::calcOpticalFlowFarneback, in its argument order. */
+typedef struct rc_farneback_params {
+    double pyr_scale;
+    int levels;
+    int winsize;
+    int iterations;
+    int poly_n;
+    double poly_sigma;
+    int flags;
+} rc_farneback_params;
+
+/* ------------------------------------------------------------------ lifetime */
+
+/* Creates a context on HIP device `device` with `max_streams` stream slots, each able to
+ * hold frames up to max_w x max_h. */
+int rcflow_create(rc_ctx** out, int device, int max_w, int max_h, int max_streams);
+void rcflow_destroy(rc_ctx* ctx);
+int rcflow_abi_version(void);
+const char* rcflow_last_error(void);
+/* Waits for everything enqueued on the slot. */
+int rcflow_sync(rc_ctx* ctx, int stream);
+/* Runs the slot on a caller-owned hipStream_t (e.g. the host framework's current
+ * stream); NULL restores the slot's own stream. */
+int rcflow_set_hip_stream(rc_ctx* ctx, int stream, void* hip_stream);
+/* Tunables: "chunk" = frame pairs per launch in clip mode (default 4);
+ * "exact_taps" = 1 keeps every polynomial-expansion tap instead of dropping taps whose
+ * total weight is below 1e-9 of the kernel mass (default 0). */
+int rcflow_set_option(rc_ctx* ctx, const char* name, int value);
+
+/* ------------------------------------------------------------------ A: Farneback
+ * Replaces  cv::calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize,
+ *           iterations, poly_n, poly_sigma, flags)
+ * as called at ripcurrents.cpp:215, main.cpp:264,609,742,961,1119,1481,
+ * ripcurrents_module.cpp:712, main_old.cpp:324 (8UC1 in, CV_32FC2 out). */
+int rcflow_farneback_u8(rc_ctx* ctx, int stream, const uint8_t* prev, size_t prev_step,
+                        const uint8_t* next, size_t next_step, int w, int h, float* flow_xy,
+                        size_t flow_step, double pyr_scale, int levels, int winsize,
+                        int iterations, int poly_n, double poly_sigma, int flags);
+/* Same, device pointers, asynchronous. */
+int rcflow_farneback_dev(rc_ctx* ctx, int stream, const uint8_t* d_prev, size_t prev_step,
+                         const uint8_t* d_next, size_t next_step, int w, int h,
+                         float* d_flow_xy, size_t flow_step, const rc_farneback_params* p);
+/* Streaming form of the frame loop ripcurrents.cpp:194-221 (`u_f1.copyTo(u_f2)` at :216):
+ * the slot keeps the previous frame's polynomial expansion, so each call does one
+ * pyramid + expansion.  The first call after rcflow_stream_reset only primes the state
+ * and writes no flow (returns 1 instead of RC_OK). */
+int rcflow_push_frame_dev(rc_ctx* ctx, int stream, const uint8_t* d_frame, size_t step,
+                          int w, int h, float* d_flow_xy, size_t flow_step,
+                          const rc_farneback_params* p);
+int rcflow_stream_reset(rc_ctx* ctx, int stream);
+/* A whole resident clip: nframes frames -> nframes-1 flow fields (pair t = frames t,t+1),
+ * processed `chunk` pairs per launch.  The bench path. */
+int rcflow_farneback_clip_dev(rc_ctx* ctx, int stream, const uint8_t* d_frames,
+                              size_t frame_stride, size_t step, int nframes, int w, int h,
+                              float* d_flows_xy, size_t flow_frame_stride, size_t flow_step,
+                              const rc_farneback_params* p);
+/* Level geometry actually used (levels cropped at min_size 32, cvRound sizes).
+ * Returns the cropped `levels`; scales are k = 0..levels. */
+int rcflow_level_geometry(int w, int h, double pyr_scale, int levels, int k, int* wk, int* hk);
+
+/* Stage-level entry points (device pointers; used by the parity tests to compare each
+ * kernel with the oracle stage by stage; interleaved layouts as in OpenCV). */
+int rcflow_stage_pyr_level_dev(rc_ctx* ctx, int stream, const uint8_t* d_img, size_t step,
+                               int w, int h, double pyr_scale, int k, float* d_out /* hk*wk */);
+int rcflow_stage_polyexp_dev(rc_ctx* ctx, int stream, const float* d_I, int w, int h,
+                             int poly_n, double poly_sigma, float* d_R5 /* h*w*5 */);
+/* One FarnebackUpdateMatrices + FarnebackUpdateFlow_* application:
+ * flow_out = solve(blur(M(R0, R1, flow_in))) */
+int rcflow_stage_flow_iter_dev(rc_ctx* ctx, int stream, const float* d_R0_5,
+                               const float* d_R1_5, const float* d_flow_in, int w, int h,
+                               int winsize, int flags, float* d_flow_out);
+
+/* ------------------------------------------------------------------ B: analysis
+ * Per-slot device-resident state mirrors the locals of ripcurrents.cpp:133-176:
+ * hist/hist2d/histsum/histsum2d (cumulative, never reset by the reference), UPPER (=100
+ * initially), UPPER2d, prop_above_upper, accumulator, streamlines_mat/_distance. */
+int rcflow_analysis_reset(rc_ctx* ctx, int stream, int w, int h);
+
+/* Replaces the counting loop of create_histogram (ripcurrents_module.cpp:94-107,
+ * ripcurrents.cpp:319-330) fused with the polar conversion ripcurrents.cpp:305-309.
+ * Adds this flow field's counts to the slot's cumulative histogram. */
+int rcflow_histogram_dev(rc_ctx* ctx, int stream, const float* d_flow_xy, size_t flow_step,
+                         int w, int h);
+/* Replaces the threshold scans of create_histogram (ripcurrents_module.cpp:109-144):
+ * derives UPPER, UPPER2d[36], prop_above_upper[36] on the device from the slot's counts. */
+int rcflow_thresholds_dev(rc_ctx* ctx, int stream);
+/* Copies the slot's histogram words (RC_HIST_WORDS int32: hist, hist2d, histsum,
+ * histsum2d) and thresholds to the host; any pointer may be NULL.  Synchronises. */
+int rcflow_histogram_read(rc_ctx* ctx, int stream, int32_t* hist, int32_t* hist2d,
+                          int32_t* histsum, int32_t* histsum2d, float* UPPER, float* UPPER2d,
+                          float* prop_above_upper);
+int rcflow_histogram_write(rc_ctx* ctx, int stream, const int32_t* words /* RC_HIST_WORDS */);
+/* Device address of the RC_HIST_WORDS int32 block (for an RCCL all-reduce issued by the
+ * host framework on the slot's stream). */
+int rcflow_histogram_device_ptr(rc_ctx* ctx, int stream, int32_t** d_words);
+
+/* Replaces create_flow + create_accumulationbuffer (ripcurrents_module.cpp:153-212,
+ * ripcurrents.cpp:376-439) fused with the polar conversion.  Uses the slot's UPPER /
+ * UPPER2d; MID/LOWER are ripcurrents.cpp:142-143.  Optional outputs (device, may be
+ * NULL): polar_hsv 32FC3 (angle, sat, val rescaled: the `current` the reference displays),
+ * waterclass 32FC3, out 32FC3, outmask 8UC1.  The slot's accumulator (.x channel of the
+ * reference's 32FC3 accumulator) is updated when framecount > 30. */
+int rcflow_classify_accumulate_dev(rc_ctx* ctx, int stream, const float* d_flow_xy,
+                                   size_t flow_step, int w, int h, int framecount, float MID,
+                                   float LOWER, float* d_polar_hsv, size_t polar_step,
+                                   float* d_waterclass, size_t wc_step, float* d_out,
+                                   size_t out_step, uint8_t* d_outmask, size_t mask_step);
+int rcflow_accumulator_read(rc_ctx* ctx, int stream, float* acc /* h*w */);
+
+/* Replaces streamlines_mat.forEach(streamline_field(...)) ripcurrents.cpp:229-231
+ * (ripcurrents_module.cpp:608-648): one particle per pixel, state in the slot.
+ * UPPER < 0 means "use the slot's current UPPER" (the value the previous frame's
+ * histogram produced, as in the reference's call order). */
+int rcflow_advect_field_dev(rc_ctx* ctx, int stream, const float* d_flow_xy, size_t flow_step,
+                            int w, int h, float dt, int iterations, float UPPER);
+int rcflow_advect_field_read(rc_ctx* ctx, int stream, float* pt_xy /* h*w*2 */,
+                             float* dist /* h*w */);
+/* Replaces the seed loops over streamline()/streamline_2()/streamline_3()/pathlines
+ * (ripcurrents.cpp:283-285, ripcurrents_module.cpp:72-75): variants
+ * 0 ripcurrents_module.cpp:486-528, 1 :531-569, 2 :572-606, 3 ripcurrents.cpp:656-698,
+ * 4 pathlines.cpp:9-46.  d_pts is n x (x,y), updated in place; d_trace (optional)
+ * receives the position after every step (n*iters*2 floats) for the host to draw. */
+int rcflow_advect_points_dev(rc_ctx* ctx, int stream, float* d_pts, int n,
+                             const float* d_flow_xy, size_t flow_step, int w, int h, float dt,
+                             int iterations, float UPPER, int variant, float* d_trace);
+/* get_delta over every pixel (ripcurrents_module.cpp:395-397,650-679). */
+int rcflow_get_delta_field_dev(rc_ctx* ctx, int stream, float* d_pt_xy, size_t pt_step,
+                               const float* d_flow_xy, size_t flow_step, int w, int h,
+                               float dt, float UPPER);
+
+/* Flow-field post-ops (in place on device flow fields) */
+int rcflow_subtract_average_dev(rc_ctx* ctx, int stream, float* d_flow_xy, size_t flow_step,
+                                int w, int h);                 /* ripcurrents_module.cpp:810-898 */
+int rcflow_subtract_mean_magnitude_dev(rc_ctx* ctx, int stream, float* d_flow_xy,
+                                       size_t flow_step, int w, int h);   /* :900-1015 */
+int rcflow_stabilizer_dev(rc_ctx* ctx, int stream, float* d_flow_xy, size_t flow_step, int w,
+                          int h);                              /* :279-308 */
+int rcflow_window_mean_dev(rc_ctx* ctx, int stream, float* d_avg, float* d_slot,
+                           const float* d_cur, size_t n, int window);     /* main.cpp:1142-1153 */
+/* Colouring: HSV triples as the reference builds them before cvtColor(HSV2BGR). */
+int rcflow_vector_to_color_dev(rc_ctx* ctx, int stream, const float* d_flow_xy,
+                               size_t flow_step, int w, int h, uint8_t* d_hsv, size_t hsv_step,
+                               float* max_displacement_io);    /* :1017-1057 */
+int rcflow_shear_rate_to_color_dev(rc_ctx* ctx, int stream, const float* d_flow_xy,
+                                   size_t flow_step, int w, int h, uint8_t* d_hsv,
+                                   size_t hsv_step, float* max_frobenius_io); /* :1059-1138 */
+
+/* ------------------------------------------------------------------ measurement */
+/* When enabled every kernel launch is bracketed by HIP events on the slot's stream. */
+int rcflow_profile_enable(rc_ctx* ctx, int on);
+int rcflow_profile_reset(rc_ctx* ctx);
+/* Resolves pending events and returns per-kernel totals.  names[i] points to a static
+ * string "kernel@level"; returns the number of entries written (<= cap). */
+int rcflow_profile_read(rc_ctx* ctx, int cap, const char** names, int* launches,
+                        double* total_ms, double* alg_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,134 @@
+/*
+ * rc_oracle.h -- C interface of the CPU oracle (TEST INFRASTRUCTURE, NOT PRODUCT).
+ *
+ * PARITY UNPINNED: the reference (borgor/ripcurrents) holds no golden vectors,
+ * fixtures or tests for this path, and the Farneback arithmetic lives in
+ * un-vendored OpenCV 4.1.0 (modules/video/src/optflow.cpp, imgproc smooth/resize,
+ * core mathfuncs), absent from /root/reference and from this image.  This oracle
+ * restates those published algorithms; it is pinned only by the analytic
+ * known-answer tests in tests/ (see DESIGN.md "Oracle").
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library.  The product (librcflow.so) never links or calls it.
+ *
+ * Layouts follow cv::Mat: interleaved channels, row pointer + byte step.
+ */
+#ifndef RC_ORACLE_H
+#define RC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_FARNEBACK_GAUSSIAN 256 /* cv::OPTFLOW_FARNEBACK_GAUSSIAN */
+#define ORC_HIST_BINS 50           /* ripcurrents.hpp:7 */
+#define ORC_HIST_DIRECTIONS 36     /* ripcurrents.hpp:8 */
+#define ORC_HIST_RESOLUTION 20     /* ripcurrents.hpp:9 */
+
+/* ---- A rows: Farneback (OpenCV 4.1.0 CPU path; call site ripcurrents.cpp:215) ---- */
+
+/* cv::calcOpticalFlowFarneback(prev,next,flow,...) on 8UC1 inputs, CV_32FC2 out.
+ * nthreads>1 row-stripes the stages that have no cross-row state. */
+int orc_farneback_u8(const uint8_t* prev, size_t prev_step, const uint8_t* next,
+                     size_t next_step, int w, int h, float* flow, size_t flow_step,
+                     double pyr_scale, int levels, int winsize, int iters, int poly_n,
+                     double poly_sigma, int flags, int nthreads);
+
+/* number of pyramid scales actually used (levels cropped by min_size=32) and
+ * the size of scale k; returns cropped `levels` (scales are k=0..levels). */
+int orc_level_geometry(int w, int h, double pyr_scale, int levels, int k, int* wk,
+                       int* hk, double* sigma, int* ksize);
+
+/* A1: convertTo(32F) -> GaussianBlur(ksize,sigma) -> resize(INTER_LINEAR) */
+int orc_pyr_level(const uint8_t* img, size_t step, int w, int h, double sigma, int ksize,
+                  float* out, int ow, int oh);
+/* building blocks of A1 */
+int orc_gaussian_kernel(int n, double sigma, float* k);
+int orc_gaussian_blur_f32(const float* src, int w, int h, int ksize, double sigma, float* dst);
+int orc_resize_linear_f32(const float* src, int sw, int sh, int cn, float* dst, int dw, int dh);
+
+/* A2: FarnebackPrepareGaussian / FarnebackPolyExp. g/xg/xxg have 2n+1 entries
+ * (index n is tap 0); ig = {ig11, ig03, ig33, ig55}. R is h*w*5 interleaved. */
+int orc_prepare_gaussian(int n, double sigma, float* g, float* xg, float* xxg, double* ig);
+int orc_polyexp(const float* I, int w, int h, int n, double sigma, float* R);
+
+/* A3: FarnebackUpdateMatrices over rows [y0,y1) */
+int orc_update_matrices(const float* R0, const float* R1, const float* flow, float* M,
+                        int w, int h, int y0, int y1);
+/* A4/A5 (+A6 stripe logic): FarnebackUpdateFlow_Blur / _GaussianBlur */
+int orc_update_flow_blur(const float* R0, const float* R1, float* flow, float* M, int w,
+                         int h, int block_size, int update_matrices);
+int orc_update_flow_gaussian(const float* R0, const float* R1, float* flow, float* M,
+                             int w, int h, int block_size, int update_matrices);
+
+/* ---- B rows: per-pixel analysis (arithmetic in the reference itself) ---- */
+
+/* B1 ripcurrents.cpp:305-309: cartToPolar(x,y,mag,angle,degrees) -> (angle,mag,mag) */
+void orc_fast_atan2_deg(const float* y, const float* x, float* angle, int n);
+void orc_flow_to_polar(const float* flow, size_t flow_step, int w, int h, float* polar,
+                       size_t polar_step);
+
+/* B2 ripcurrents_module.cpp:89-107 (counts) and :109-144 (thresholds).
+ * hist2d is [36][50] row-major. A direction index of 36 (angle==360.0f, an
+ * out-of-bounds write in the reference) is folded into direction 0. */
+void orc_histogram_accumulate(const float* polar, size_t polar_step, int w, int h,
+                              int32_t* hist, int32_t* histsum, int32_t* hist2d,
+                              int32_t* histsum2d);
+void orc_histogram_thresholds(const int32_t* hist, int32_t histsum, const int32_t* hist2d,
+                              const int32_t* histsum2d, float* UPPER, float* UPPER2d,
+                              float* prop_above_upper);
+
+/* B3a ripcurrents_module.cpp:153-182 create_flow */
+void orc_create_flow(float* polar, size_t polar_step, float* waterclass, size_t wc_step,
+                     float* accumulator2, size_t acc2_step, int w, int h, float UPPER,
+                     float MID, float LOWER, const float* UPPER2d);
+/* B3b ripcurrents_module.cpp:189-212 create_accumulationbuffer */
+void orc_create_accumulationbuffer(float* accumulator, size_t acc_step,
+                                   const float* accumulator2, size_t acc2_step, float* out,
+                                   size_t out_step, uint8_t* outmask, size_t mask_step,
+                                   int w, int h, int framecount);
+
+/* B4 ripcurrents_module.cpp:608-648 streamline_field over every pixel */
+void orc_streamline_field(float* pt, size_t pt_step, float* dist, size_t dist_step,
+                          const float* flow, size_t flow_step, int w, int h, float dt,
+                          int iterations, float UPPER);
+/* B5: seed advection. variant 0 = ripcurrents_module.cpp:486-528 (step delta*dt,
+ * cutoff r>UPPER); 1 = :531-569 (delta*dt, cutoff r>5); 2 = :572-606 (100 fixed
+ * iterations, delta*0.1, no cutoff); 3 = ripcurrents.cpp:656-698 (delta*dt/iters,
+ * cutoff r>UPPER); 4 = pathlines.cpp:9-46 (delta*dt/iters, no cutoff).
+ * pts is n x (x,y). trace (optional) receives n*iters*2 positions after each step
+ * (unchanged position repeated once a particle has stopped). */
+void orc_streamline_points(float* pts, int n, const float* flow, size_t flow_step, int w,
+                           int h, float dt, int iterations, float UPPER, int variant,
+                           float* trace);
+/* get_delta ripcurrents_module.cpp:650-679 over every pixel (averageVector :395-397) */
+void orc_get_delta_field(float* pt, size_t pt_step, const float* flow, size_t flow_step,
+                         int w, int h, float dt, float UPPER);
+
+/* B6 Streakline.cpp:22-71 bookkeeping with the vertices moved through a dense
+ * flow field (main.cpp:961-977 precedent) instead of PyrLK.  verts holds
+ * *nverts (x,y) pairs, capacity >= *nverts+1. */
+void orc_streakline_step(float* verts, int* nverts, float gen_x, float gen_y,
+                         const float* flow, size_t flow_step, int w, int h, float dt,
+                         int* frame_count);
+
+/* B7 post-ops */
+void orc_subtract_average(float* flow, size_t flow_step, int w, int h);          /* :810-898 */
+void orc_subtract_mean_magnitude(float* flow, size_t flow_step, int w, int h);   /* :900-1015 */
+void orc_stabilizer(float* flow, size_t flow_step, int w, int h);                /* :279-308 */
+void orc_window_mean_update(float* avg, float* slot, const float* cur, int n,    /* main.cpp:1142-1153 */
+                            int window);
+
+/* B8 colouring (HSV triples, before the cvtColor display step) */
+void orc_vector_to_color(const float* flow, size_t flow_step, int w, int h, uint8_t* hsv,
+                         size_t hsv_step, float* max_displacement);               /* :1017-1057 */
+void orc_shear_rate_to_color(const float* flow, size_t flow_step, int w, int h,
+                             uint8_t* hsv, size_t hsv_step, float* max_frobenius); /* :1059-1138 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

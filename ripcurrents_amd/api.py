@@ -1,0 +1,411 @@
+"""Host-side mirror of the reference's interface for the hot path, over librcflow's C ABI.
+
+Names, argument order and meaning follow the reference (paths relative to
+/root/reference/RipCurrents_main):
+  calcOpticalFlowFarneback   cv:: call at ripcurrents.cpp:215, main.cpp:264,...
+  create_histogram           ripcurrents_module.cpp:89-144   (ripcurrents.hpp:39)
+  create_flow                ripcurrents_module.cpp:153-182  (ripcurrents.hpp:50)
+  create_accumulationbuffer  ripcurrents_module.cpp:189-212  (ripcurrents.hpp:52)
+  streamline_field           ripcurrents_module.cpp:608-648  (ripcurrents.hpp:22)
+  streamline / _2 / _3       ripcurrents_module.cpp:486-606  (ripcurrents.hpp:23-25)
+  get_delta                  ripcurrents_module.cpp:650-679  (ripcurrents.hpp:58)
+  Streakline                 Streakline.hpp:8-20, Streakline.cpp:11-71
+  subtructAverage / subtructMeanMagnitude / stabilizer / vectorToColor / shearRateToColor
+
+torch is used for device memory and streams only; all compute is in the HIP library.
+Arrays cross this layer as torch CUDA tensors (zero copy) or numpy arrays (copied).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import FarnebackParams, HIST_BINS, HIST_DIRECTIONS, HIST_WORDS, check
+
+__all__ = ["Context", "FarnebackParams", "Streakline", "HistState"]
+
+
+def _params(pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags):
+    return FarnebackParams(float(pyr_scale), int(levels), int(winsize), int(iterations), int(poly_n),
+                           float(poly_sigma), int(flags))
+
+
+def _is_t(x):
+    return isinstance(x, torch.Tensor)
+
+
+class HistState:
+    """Host copy of the caller-owned arrays of create_histogram (ripcurrents.cpp:147-154)."""
+
+    def __init__(self):
+        self.hist = np.zeros(HIST_BINS, np.int32)
+        self.histsum = 0
+        self.hist2d = np.zeros((HIST_DIRECTIONS, HIST_BINS), np.int32)
+        self.histsum2d = np.zeros(HIST_DIRECTIONS, np.int32)
+        self.UPPER = 100.0
+        self.UPPER2d = np.zeros(HIST_DIRECTIONS, np.float32)
+        self.prop_above_upper = np.zeros(HIST_DIRECTIONS, np.float32)
+
+
+class Context:
+    """One GPU context with `streams` independent stream slots (rcflow_create)."""
+
+    def __init__(self, max_w, max_h, device=0, streams=1):
+        self._lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("ripcurrents_amd needs a HIP device; there is no CPU fallback")
+        self.device = torch.device("cuda", device)
+        h = C.c_void_p()
+        check(self._lib.rcflow_create(C.byref(h), device, max_w, max_h, streams))
+        self._h = h
+        self.max_w, self.max_h = max_w, max_h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rcflow_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ------------------------------------------------------------------ plumbing
+    def sync(self, stream=0):
+        check(self._lib.rcflow_sync(self._h, stream))
+
+    def use_torch_stream(self, stream=0, torch_stream=None):
+        """Run the slot on a torch stream (default: torch's current stream)."""
+        ts = torch_stream if torch_stream is not None else torch.cuda.current_stream(self.device)
+        check(self._lib.rcflow_set_hip_stream(self._h, stream, C.c_void_p(ts.cuda_stream)))
+
+    def use_own_stream(self, stream=0):
+        check(self._lib.rcflow_set_hip_stream(self._h, stream, None))
+
+    def set_option(self, name, value):
+        check(self._lib.rcflow_set_option(self._h, name.encode(), int(value)))
+
+    def _dev(self, a, dtype):
+        if _is_t(a):
+            if not a.is_cuda or a.dtype != dtype:
+                raise TypeError("expected a CUDA tensor of dtype %s" % dtype)
+            return a
+        return torch.as_tensor(np.ascontiguousarray(a)).to(self.device, dtype)
+
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t.data_ptr())
+
+    # ------------------------------------------------------------------ A: Farneback
+    def calcOpticalFlowFarneback(self, prev, next, flow=None, pyr_scale=0.5, levels=2, winsize=3,
+                                 iterations=2, poly_n=15, poly_sigma=1.2, flags=0, stream=0):
+        """cv::calcOpticalFlowFarneback(prev, next, flow, ...) -> flow (HxWx2 float32).
+
+        numpy inputs use the host-pointer entry point (copy in, compute, copy out);
+        CUDA tensors use the device entry point and return a CUDA tensor (asynchronous).
+        """
+        if _is_t(prev):
+            if prev.shape != next.shape or prev.dim() != 2:
+                raise ValueError("prev and next must be HxW and equal in size")
+            h, w = prev.shape
+            if flow is None:
+                flow = torch.empty((h, w, 2), dtype=torch.float32, device=prev.device)
+            p = _params(pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags)
+            check(self._lib.rcflow_farneback_dev(
+                self._h, stream, self._ptr(prev), prev.stride(0), self._ptr(next), next.stride(0), w, h,
+                self._ptr(flow), flow.stride(0) * 4, C.byref(p)))
+            return flow
+        prev = np.asarray(prev)
+        next = np.asarray(next)
+        if prev.dtype != np.uint8 or next.dtype != np.uint8 or prev.ndim != 2 or prev.shape != next.shape:
+            raise ValueError("prev and next must be HxW uint8 and equal in size")
+        if prev.strides[1] != 1:
+            prev = np.ascontiguousarray(prev)
+        if next.strides[1] != 1:
+            next = np.ascontiguousarray(next)
+        h, w = prev.shape
+        if flow is None:
+            flow = np.empty((h, w, 2), np.float32)
+        check(self._lib.rcflow_farneback_u8(
+            self._h, stream, prev.ctypes.data, prev.strides[0], next.ctypes.data, next.strides[0], w, h,
+            flow.ctypes.data, flow.strides[0], pyr_scale, levels, winsize, iterations, poly_n, poly_sigma,
+            flags))
+        return flow
+
+    def push_frame(self, frame, flow=None, stream=0, **kw):
+        """Streaming frame loop (ripcurrents.cpp:194-221): returns None for the first frame."""
+        frame = self._dev(frame, torch.uint8)
+        h, w = frame.shape
+        p = _params(kw.get("pyr_scale", 0.5), kw.get("levels", 2), kw.get("winsize", 3),
+                    kw.get("iterations", 2), kw.get("poly_n", 15), kw.get("poly_sigma", 1.2),
+                    kw.get("flags", 0))
+        if flow is None:
+            flow = torch.empty((h, w, 2), dtype=torch.float32, device=frame.device)
+        rc = check(self._lib.rcflow_push_frame_dev(self._h, stream, self._ptr(frame), frame.stride(0), w, h,
+                                                   self._ptr(flow), flow.stride(0) * 4, C.byref(p)))
+        return None if rc == 1 else flow
+
+    def stream_reset(self, stream=0):
+        check(self._lib.rcflow_stream_reset(self._h, stream))
+
+    def farneback_clip(self, frames, flows=None, stream=0, pyr_scale=0.5, levels=2, winsize=3, iterations=2,
+                       poly_n=15, poly_sigma=1.2, flags=0):
+        """[T,H,W] uint8 CUDA clip -> [T-1,H,W,2] flows (pair t = frames t, t+1)."""
+        frames = self._dev(frames, torch.uint8)
+        T, h, w = frames.shape
+        if flows is None:
+            flows = torch.empty((T - 1, h, w, 2), dtype=torch.float32, device=frames.device)
+        p = _params(pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags)
+        check(self._lib.rcflow_farneback_clip_dev(
+            self._h, stream, self._ptr(frames), frames.stride(0), frames.stride(1), T, w, h,
+            self._ptr(flows), flows.stride(0) * 4, flows.stride(1) * 4, C.byref(p)))
+        return flows
+
+    def level_geometry(self, w, h, pyr_scale, levels, k):
+        wk, hk = C.c_int(), C.c_int()
+        L = check(self._lib.rcflow_level_geometry(w, h, pyr_scale, levels, k, C.byref(wk), C.byref(hk)))
+        return L, wk.value, hk.value
+
+    # stage-level entry points (parity tests)
+    def stage_pyr_level(self, img, pyr_scale, k, stream=0):
+        img = self._dev(img, torch.uint8)
+        h, w = img.shape
+        _, wk, hk = self.level_geometry(w, h, pyr_scale, 64, k)
+        out = torch.empty((hk, wk), dtype=torch.float32, device=self.device)
+        check(self._lib.rcflow_stage_pyr_level_dev(self._h, stream, self._ptr(img), img.stride(0), w, h,
+                                                   pyr_scale, k, self._ptr(out)))
+        return out
+
+    def stage_polyexp(self, I, poly_n=15, poly_sigma=1.2, stream=0):
+        I = self._dev(I, torch.float32).contiguous()
+        h, w = I.shape
+        R = torch.empty((h, w, 5), dtype=torch.float32, device=self.device)
+        check(self._lib.rcflow_stage_polyexp_dev(self._h, stream, self._ptr(I), w, h, poly_n, poly_sigma,
+                                                 self._ptr(R)))
+        return R
+
+    def stage_flow_iter(self, R0, R1, flow_in, winsize, flags, stream=0):
+        R0 = self._dev(R0, torch.float32).contiguous()
+        R1 = self._dev(R1, torch.float32).contiguous()
+        h, w = R0.shape[:2]
+        fin = None if flow_in is None else self._dev(flow_in, torch.float32).contiguous()
+        out = torch.empty((h, w, 2), dtype=torch.float32, device=self.device)
+        check(self._lib.rcflow_stage_flow_iter_dev(self._h, stream, self._ptr(R0), self._ptr(R1),
+                                                   None if fin is None else self._ptr(fin), w, h, winsize,
+                                                   flags, self._ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ B: analysis
+    def analysis_reset(self, w, h, stream=0):
+        check(self._lib.rcflow_analysis_reset(self._h, stream, w, h))
+
+    def _flow(self, flow):
+        flow = self._dev(flow, torch.float32)
+        if flow.dim() != 3 or flow.shape[2] != 2 or flow.stride(2) != 1 or flow.stride(1) != 2:
+            flow = flow.contiguous()
+        return flow
+
+    def create_histogram(self, current, st=None, stream=0):
+        """create_histogram(current, hist, histsum, hist2d, histsum2d, UPPER, UPPER2d, prop_above_upper).
+
+        `current` is the flow field (HxWx2); the polar conversion the reference does first
+        (ripcurrents.cpp:305-309) is fused into the kernel.  The cumulative counters live in the
+        slot; `st` (HistState) receives a host copy, like the reference's in/out arrays.
+        """
+        flow = self._flow(current)
+        h, w = flow.shape[:2]
+        check(self._lib.rcflow_histogram_dev(self._h, stream, self._ptr(flow), flow.stride(0) * 4, w, h))
+        check(self._lib.rcflow_thresholds_dev(self._h, stream))
+        if st is not None:
+            self.histogram_read(st, stream)
+        return st
+
+    def histogram_accumulate(self, current, stream=0):
+        flow = self._flow(current)
+        h, w = flow.shape[:2]
+        check(self._lib.rcflow_histogram_dev(self._h, stream, self._ptr(flow), flow.stride(0) * 4, w, h))
+
+    def thresholds(self, stream=0):
+        check(self._lib.rcflow_thresholds_dev(self._h, stream))
+
+    def histogram_read(self, st=None, stream=0):
+        st = st or HistState()
+        hs, up = C.c_int32(), C.c_float()
+        check(self._lib.rcflow_histogram_read(
+            self._h, stream, st.hist.ctypes.data, st.hist2d.ctypes.data, C.addressof(hs),
+            st.histsum2d.ctypes.data, C.addressof(up), st.UPPER2d.ctypes.data,
+            st.prop_above_upper.ctypes.data))
+        st.histsum, st.UPPER = hs.value, up.value
+        return st
+
+    def histogram_words(self, stream=0):
+        """The RC_HIST_WORDS int32 block as a CUDA tensor aliasing the slot's counters
+        (what torch.distributed.all_reduce sums across ranks)."""
+        p = C.c_void_p()
+        check(self._lib.rcflow_histogram_device_ptr(self._h, stream, C.byref(p)))
+        return _alias_tensor(p.value, HIST_WORDS, torch.int32, self.device)
+
+    def histogram_write(self, words, stream=0):
+        words = np.ascontiguousarray(words, np.int32)
+        assert words.size == HIST_WORDS
+        check(self._lib.rcflow_histogram_write(self._h, stream, words.ctypes.data))
+
+    def create_flow_accumulate(self, current, framecount, MID=0.5, LOWER=0.2, want=("polar", "waterclass",
+                               "out", "outmask"), stream=0):
+        """create_flow + create_accumulationbuffer (ripcurrents_module.cpp:153-212) in one pass.
+        Returns a dict of the requested device outputs."""
+        flow = self._flow(current)
+        h, w = flow.shape[:2]
+        outs = {}
+        def mk(name, shape, dt):
+            if name in want:
+                outs[name] = torch.empty(shape, dtype=dt, device=self.device)
+                return self._ptr(outs[name]), outs[name].stride(0) * outs[name].element_size()
+            return None, 0
+        pp, ps = mk("polar", (h, w, 3), torch.float32)
+        wp, ws = mk("waterclass", (h, w, 3), torch.float32)
+        op, os_ = mk("out", (h, w, 3), torch.float32)
+        mp, ms = mk("outmask", (h, w), torch.uint8)
+        check(self._lib.rcflow_classify_accumulate_dev(
+            self._h, stream, self._ptr(flow), flow.stride(0) * 4, w, h, framecount, MID, LOWER, pp, ps, wp, ws,
+            op, os_, mp, ms))
+        return outs
+
+    def accumulator(self, w, h, stream=0):
+        acc = np.empty((h, w), np.float32)
+        check(self._lib.rcflow_accumulator_read(self._h, stream, acc.ctypes.data))
+        return acc
+
+    def streamline_field(self, flow, dt, iterations, UPPER=-1.0, stream=0):
+        """streamlines_mat.forEach(streamline_field(...)) ripcurrents.cpp:229-231; state in the slot."""
+        flow = self._flow(flow)
+        h, w = flow.shape[:2]
+        check(self._lib.rcflow_advect_field_dev(self._h, stream, self._ptr(flow), flow.stride(0) * 4, w, h, dt,
+                                                iterations, UPPER))
+
+    def streamline_field_state(self, w, h, stream=0):
+        pt = np.empty((h, w, 2), np.float32)
+        dist = np.empty((h, w), np.float32)
+        check(self._lib.rcflow_advect_field_read(self._h, stream, pt.ctypes.data, dist.ctypes.data))
+        return pt, dist
+
+    def streamline(self, pts, flow, dt, iterations, UPPER, variant=0, trace=False, stream=0):
+        """Seed loops over streamline()/streamline_2()/streamline_3() (variant 0/1/2),
+        ripcurrents.cpp's copy (3) and pathlines.cpp (4).  pts: n x 2, returns (pts, trace)."""
+        flow = self._flow(flow)
+        h, w = flow.shape[:2]
+        d_pts = self._dev(np.ascontiguousarray(pts, np.float32) if not _is_t(pts) else pts, torch.float32).contiguous()
+        n = d_pts.shape[0]
+        iters = 100 if variant == 2 else iterations
+        tr = torch.zeros((n, iters, 2), dtype=torch.float32, device=self.device) if trace else None
+        check(self._lib.rcflow_advect_points_dev(
+            self._h, stream, self._ptr(d_pts), n, self._ptr(flow), flow.stride(0) * 4, w, h, dt, iterations,
+            UPPER, variant, None if tr is None else self._ptr(tr)))
+        return d_pts, tr
+
+    def get_delta_field(self, pt, flow, dt, UPPER, stream=0):
+        flow = self._flow(flow)
+        h, w = flow.shape[:2]
+        pt = self._dev(pt, torch.float32).contiguous()
+        check(self._lib.rcflow_get_delta_field_dev(self._h, stream, self._ptr(pt), pt.stride(0) * 4,
+                                                   self._ptr(flow), flow.stride(0) * 4, w, h, dt, UPPER))
+        return pt
+
+    def _postop(self, fn, current, stream):
+        flow = self._flow(current)
+        h, w = flow.shape[:2]
+        check(fn(self._h, stream, self._ptr(flow), flow.stride(0) * 4, w, h))
+        return flow
+
+    def subtructAverage(self, current, stream=0):
+        return self._postop(self._lib.rcflow_subtract_average_dev, current, stream)
+
+    def subtructMeanMagnitude(self, current, stream=0):
+        return self._postop(self._lib.rcflow_subtract_mean_magnitude_dev, current, stream)
+
+    def stabilizer(self, current, stream=0):
+        return self._postop(self._lib.rcflow_stabilizer_dev, current, stream)
+
+    def window_mean(self, avg, slot, cur, window, stream=0):
+        check(self._lib.rcflow_window_mean_dev(self._h, stream, self._ptr(avg), self._ptr(slot), self._ptr(cur),
+                                               avg.numel(), window))
+
+    def vectorToColor(self, current, max_displacement, stream=0):
+        flow = self._flow(current)
+        h, w = flow.shape[:2]
+        hsv = torch.zeros((h, w, 3), dtype=torch.uint8, device=self.device)
+        md = C.c_float(max_displacement)
+        check(self._lib.rcflow_vector_to_color_dev(self._h, stream, self._ptr(flow), flow.stride(0) * 4, w, h,
+                                                   self._ptr(hsv), hsv.stride(0), C.byref(md)))
+        return hsv, md.value
+
+    def shearRateToColor(self, current, max_frobenius, hsv=None, stream=0):
+        flow = self._flow(current)
+        h, w = flow.shape[:2]
+        if hsv is None:
+            hsv = torch.zeros((h, w, 3), dtype=torch.uint8, device=self.device)
+        mf = C.c_float(max_frobenius)
+        check(self._lib.rcflow_shear_rate_to_color_dev(self._h, stream, self._ptr(flow), flow.stride(0) * 4, w, h,
+                                                       self._ptr(hsv), hsv.stride(0), C.byref(mf)))
+        return hsv, mf.value
+
+    # ------------------------------------------------------------------ measurement
+    def profile_enable(self, on=True):
+        check(self._lib.rcflow_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(self._lib.rcflow_profile_reset(self._h))
+
+    def profile_read(self):
+        cap = 256
+        names = (C.c_char_p * cap)()
+        launches = (C.c_int * cap)()
+        ms = (C.c_double * cap)()
+        by = (C.c_double * cap)()
+        n = check(self._lib.rcflow_profile_read(self._h, cap, names, launches, ms, by))
+        return [dict(kernel=names[i].decode(), launches=launches[i], total_ms=ms[i], alg_bytes=by[i])
+                for i in range(n)]
+
+
+def _alias_tensor(ptr, n, dtype, device):
+    """A torch tensor aliasing `n` elements of device memory the library owns."""
+    itemsize = torch.empty((), dtype=dtype).element_size()
+
+    class _Holder:
+        __cuda_array_interface__ = {"shape": (n,), "typestr": "<i%d" % itemsize if dtype != torch.float32 else "<f4",
+                                    "data": (ptr, False), "version": 2}
+    return torch.as_tensor(_Holder(), device=device)
+
+
+class Streakline:
+    """Streakline.hpp:8-20 / Streakline.cpp:11-71 with the vertices moved through the dense
+    flow field (the compute_timelinesFarne precedent, main.cpp:961-977) instead of sparse LK.
+    Fields as in the reference: generationPoint, vertices, numberOfVertices, frameCount."""
+
+    def __init__(self, pixel):
+        self.generationPoint = (float(pixel[0]), float(pixel[1]))
+        self.vertices = [self.generationPoint]
+        self.numberOfVertices = 1
+        self.frameCount = 1
+
+    def run(self, ctx, flow, width, height, dt=1.0, stream=0):
+        """runLK's bookkeeping: move every vertex, reject jumps > 0.1*dim (Streakline.cpp:35-40),
+        insert the generation point in front (:46-48)."""
+        v = np.asarray(self.vertices, np.float32).reshape(-1, 2)
+        # variant 4 = `p += delta*dt/iterations` with no cutoff; one step
+        moved, _ = ctx.streamline(v, flow, dt, 1, 0.0, variant=4, stream=stream)
+        nxt = moved.cpu().numpy()
+        big = (np.abs(v[:, 0] - nxt[:, 0]) > width * 0.1) | (np.abs(v[:, 1] - nxt[:, 1]) > height * 0.1)
+        nxt[big] = v[big]
+        self.vertices = [self.generationPoint] + [tuple(map(float, p)) for p in nxt]
+        self.numberOfVertices = len(self.vertices)
+        self.frameCount += 1
+        return self.vertices

@@ -1,0 +1,773 @@
+// analysis_kernels.hip -- gfx950 kernels and C ABI for the per-pixel analysis that consumes
+// the flow field.  Reference arithmetic:
+//   B1 ripcurrents.cpp:305-309 (cartToPolar, degrees)      B2 ripcurrents_module.cpp:89-144
+//   B3 ripcurrents_module.cpp:153-212                       B4 ripcurrents_module.cpp:608-648
+//   B5 ripcurrents_module.cpp:486-606,650-679; ripcurrents.cpp:656-698; pathlines.cpp:9-46
+//   B7 ripcurrents_module.cpp:279-308,810-1015; main.cpp:1142-1153
+//   B8 ripcurrents_module.cpp:1017-1138
+// These are HBM-bound integer/float per-pixel passes: the polar conversion is fused into
+// its consumers (never materialised), counts are privatised in LDS, thresholds stay on the
+// device so the frame loop never synchronises with the host.
+// Compiled with -ffp-contract=off: every float expression rounds as the reference's does,
+// which makes bins, classes and particle positions bit-exact for identical flow input.
+
+#include <cfloat>
+#include <climits>
+#include <cstring>
+#include <vector>
+
+#include "rc_host.h"
+
+#define RC_BLOCK 256
+#define THR_UPPER 0
+#define THR_UPPER2D 1
+#define THR_PROP (1 + RC_HIST_DIRECTIONS)
+#define THR_WORDS (1 + 2 * RC_HIST_DIRECTIONS)
+
+// OpenCV core fastAtan32f (degrees), mathfuncs_core: 7th-order odd polynomial.
+__device__ __forceinline__ float rc_fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// int angle = (a * HIST_DIRECTIONS) / 360 (ripcurrents_module.cpp:100); 36 (a == 360.0f, an
+// out-of-bounds index in the reference) folds to direction 0.
+__device__ __forceinline__ int rc_dir_index(float angle) {
+    int d = (int)((angle * RC_HIST_DIRECTIONS) / 360);
+    if (d >= RC_HIST_DIRECTIONS || d < 0) d = 0;
+    return d;
+}
+
+__device__ __forceinline__ const float2* rc_row2(const float* base, size_t step, int y) {
+    return (const float2*)((const char*)base + (size_t)y * step);
+}
+
+// ============================================================================ B1+B2 histogram
+// One LDS atomic per pixel on a block-private hist2d[36][50]; hist, histsum and histsum2d
+// are its marginals and are formed when the block flushes.
+__global__ __launch_bounds__(RC_BLOCK) void k_polar_hist(const float* flow, size_t step, int w, int h,
+                                                         int* words) {
+    __shared__ int lh[RC_HIST_DIRECTIONS * RC_HIST_BINS];
+    for (int i = threadIdx.x; i < RC_HIST_DIRECTIONS * RC_HIST_BINS; i += RC_BLOCK) lh[i] = 0;
+    __syncthreads();
+    const int w2 = (w + 1) >> 1;
+    const long long total = (long long)w2 * h;
+    for (long long i = (long long)blockIdx.x * RC_BLOCK + threadIdx.x; i < total;
+         i += (long long)gridDim.x * RC_BLOCK) {
+        int y = (int)(i / w2), x = (int)(i - (long long)y * w2) * 2;
+        const float2* r = rc_row2(flow, step, y);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (x + q < w) {
+                float2 f = r[x + q];
+                float mag = sqrtf(f.x * f.x + f.y * f.y);
+                int bin = (int)(mag * RC_HIST_RESOLUTION);
+                if (bin < RC_HIST_BINS && bin >= 0) {
+                    int dir = rc_dir_index(rc_fast_atan2_deg(f.y, f.x));
+                    atomicAdd(&lh[dir * RC_HIST_BINS + bin], 1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // words: hist[50] | hist2d[1800] | histsum | histsum2d[36]
+    int* hist = words;
+    int* hist2d = words + RC_HIST_BINS;
+    int* histsum = hist2d + RC_HIST_DIRECTIONS * RC_HIST_BINS;
+    int* histsum2d = histsum + 1;
+    for (int i = threadIdx.x; i < RC_HIST_DIRECTIONS * RC_HIST_BINS; i += RC_BLOCK) {
+        int v = lh[i];
+        if (v) atomicAdd(&hist2d[i], v);
+    }
+    if (threadIdx.x < RC_HIST_BINS) {
+        int v = 0;
+        for (int d = 0; d < RC_HIST_DIRECTIONS; d++) v += lh[d * RC_HIST_BINS + threadIdx.x];
+        if (v) atomicAdd(&hist[threadIdx.x], v);
+    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + RC_HIST_DIRECTIONS) {
+        int d = threadIdx.x - 64, v = 0;
+        for (int b = 0; b < RC_HIST_BINS; b++) v += lh[d * RC_HIST_BINS + b];
+        if (v) {
+            atomicAdd(&histsum2d[d], v);
+            atomicAdd(histsum, v);
+        }
+    }
+}
+
+// Threshold scans, ripcurrents_module.cpp:109-144, one lane per direction.
+__global__ void k_thresholds(const int* words, float* thr) {
+    const int* hist = words;
+    const int* hist2d = words + RC_HIST_BINS;
+    const int histsum = words[RC_HIST_BINS + RC_HIST_DIRECTIONS * RC_HIST_BINS];
+    const int* histsum2d = words + RC_HIST_BINS + RC_HIST_DIRECTIONS * RC_HIST_BINS + 1;
+    __shared__ int s_target, s_threshsum;
+    if (threadIdx.x == 0) {
+        int threshsum = 0, bin = RC_HIST_BINS - 1;
+        while (threshsum < (histsum * .05)) {
+            threshsum += hist[bin];
+            bin--;
+        }
+        thr[THR_UPPER] = bin / float(RC_HIST_RESOLUTION);
+        s_target = bin;
+        s_threshsum = threshsum;
+    }
+    __syncthreads();
+    int angle = threadIdx.x;
+    if (angle < RC_HIST_DIRECTIONS) {
+        int threshsum2 = 0, bin = RC_HIST_BINS - 1;
+        while (threshsum2 < (histsum2d[angle] * .05)) {
+            threshsum2 += hist2d[angle * RC_HIST_BINS + bin];
+            bin--;
+        }
+        float u = bin / float(RC_HIST_RESOLUTION);
+        if (u < 0.01) u = 0.01;
+        thr[THR_UPPER2D + angle] = u;
+        int threshsum3 = 0;
+        bin = RC_HIST_BINS - 1;
+        while (bin > s_target) {
+            threshsum3 += hist2d[angle * RC_HIST_BINS + bin];
+            bin--;
+        }
+        thr[THR_PROP + angle] = ((float)threshsum3) / s_threshsum;
+    }
+}
+
+// ============================================================================ B1+B3 classify + accumulate
+struct ClassifyArgs {
+    const float* flow; size_t flow_step;
+    int w, h, framecount;
+    float MID, LOWER;
+    const float* thr;
+    float* acc;
+    float* polar; size_t polar_step;
+    float* wclass; size_t wc_step;
+    float* out; size_t out_step;
+    uint8_t* mask; size_t mask_step;
+};
+
+__global__ __launch_bounds__(RC_BLOCK) void k_classify_accumulate(ClassifyArgs a) {
+    __shared__ float s_u2d[RC_HIST_DIRECTIONS];
+    if (threadIdx.x < RC_HIST_DIRECTIONS) s_u2d[threadIdx.x] = a.thr[THR_UPPER2D + threadIdx.x];
+    __syncthreads();
+    const float UPPER = a.thr[THR_UPPER];
+    const long long total = (long long)a.w * a.h;
+    for (long long i = (long long)blockIdx.x * RC_BLOCK + threadIdx.x; i < total;
+         i += (long long)gridDim.x * RC_BLOCK) {
+        int y = (int)(i / a.w), x = (int)(i - (long long)y * a.w);
+        float2 f = rc_row2(a.flow, a.flow_step, y)[x];
+        float val = sqrtf(f.x * f.x + f.y * f.y);
+        float ang = rc_fast_atan2_deg(f.y, f.x);
+        int dir = rc_dir_index(ang);
+        // create_flow: ripcurrents_module.cpp:162-168
+        float cx = 0.f, cy = 0.f, cz = 0.f, inc = 0.f;
+        if (val > UPPER) { cx = .5f; inc = 1.f; }
+        else if (val > a.MID) { cz = 1.f; }
+        else if (val > a.LOWER) { cz = .5f; }
+        else { cy = .5f; }
+        if (a.wclass) {
+            float* p = (float*)((char*)a.wclass + (size_t)y * a.wc_step) + 3 * x;
+            p[0] = cx; p[1] = cy; p[2] = cz;
+        }
+        if (a.polar) {
+            float zz = val / s_u2d[dir];
+            float* p = (float*)((char*)a.polar + (size_t)y * a.polar_step) + 3 * x;
+            p[0] = ang; p[1] = zz > 1 ? 1.f : .7f; p[2] = zz;
+        }
+        // create_accumulationbuffer: ripcurrents_module.cpp:191-211
+        float acc = a.acc[i];
+        if (a.framecount > 30) {
+            acc = inc + acc;
+            a.acc[i] = acc;
+        }
+        int v = (int)acc;
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+        uint8_t mk = 0;
+        if (v > .1 * a.framecount) {
+            if (v < .2 * a.framecount) oz = 1.f;
+            else ox = 1.f;
+        } else {
+            oy = .5f;
+            mk = 255;
+        }
+        if (a.out) {
+            float* p = (float*)((char*)a.out + (size_t)y * a.out_step) + 3 * x;
+            p[0] = ox; p[1] = oy; p[2] = oz;
+        }
+        if (a.mask) a.mask[(size_t)y * a.mask_step + x] = mk;
+    }
+}
+
+// ============================================================================ B4/B5 advection
+// Bilinear sampler shared by every streamline variant (ripcurrents_module.cpp:494-508).
+__device__ __forceinline__ bool rc_sample_flow(const float* flow, size_t step, int w, int h, float x, float y,
+                                               float& dx, float& dy) {
+    int xind = (int)floorf(x), yind = (int)floorf(y);
+    float xrem = x - xind, yrem = y - yind;
+    if (xind < 1 || yind < 1 || xind + 2 > w || yind + 2 > h) return false;
+    const float2* r0 = rc_row2(flow, step, yind) + xind;
+    const float2* r1 = rc_row2(flow, step, yind + 1) + xind;
+    float2 p00 = r0[0], p01 = r0[1], p10 = r1[0], p11 = r1[1];
+    float wa = 1 - xrem, wb = 1 - yrem;
+    dx = p00.x * wa * wb + p01.x * xrem * wb + p10.x * wa * yrem + p11.x * xrem * yrem;
+    dy = p00.y * wa * wb + p01.y * xrem * wb + p10.y * wa * yrem + p11.y * xrem * yrem;
+    return true;
+}
+
+__global__ __launch_bounds__(RC_BLOCK) void k_advect_field(float2* pt, float* dist, const float* flow,
+                                                           size_t step, int w, int h, float dt, int iterations,
+                                                           float UPPER_arg, const float* thr) {
+    const float UPPER = UPPER_arg < 0 ? thr[THR_UPPER] : UPPER_arg;
+    const long long total = (long long)w * h;
+    for (long long i = (long long)blockIdx.x * RC_BLOCK + threadIdx.x; i < total;
+         i += (long long)gridDim.x * RC_BLOCK) {
+        int yo = (int)(i / w), xo = (int)(i - (long long)yo * w);
+        float2 p = pt[i];
+        float d = dist[i];
+        for (int it = 0; it < iterations; it++) {
+            float x = p.x + xo, y = p.y + yo;
+            float dx, dy;
+            if (!rc_sample_flow(flow, step, w, h, x, y, dx, dy)) break;
+            float r = sqrtf(dx * dx + dy * dy);
+            if (r > UPPER) break;
+            p.x = p.x + dx * dt / iterations;
+            p.y = p.y + dy * dt / iterations;
+            d = d + r;
+        }
+        pt[i] = p;
+        dist[i] = d;
+    }
+}
+
+__global__ void k_advect_points(float2* pts, int n, const float* flow, size_t step, int w, int h, float dt,
+                                int iterations, float UPPER_arg, const float* thr, int variant, float2* trace) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const float UPPER = UPPER_arg < 0 ? thr[THR_UPPER] : UPPER_arg;
+    const int iters = variant == 2 ? 100 : iterations;
+    float2 p = pts[s];
+    bool alive = true;
+    for (int i = 0; i < iters; i++) {
+        float dx, dy;
+        if (alive && !rc_sample_flow(flow, step, w, h, p.x, p.y, dx, dy)) alive = false;
+        if (alive) {
+            float r = sqrtf(dx * dx + dy * dy);
+            if ((variant == 0 || variant == 3) && r > UPPER) alive = false;
+            if (variant == 1 && r > 5) alive = false;
+        }
+        if (alive) {
+            if (variant <= 1) { p.x = p.x + dx * dt; p.y = p.y + dy * dt; }
+            else if (variant == 2) { p.x = p.x + (float)(dx * 0.1); p.y = p.y + (float)(dy * 0.1); }
+            else { p.x = p.x + dx * dt / iterations; p.y = p.y + dy * dt / iterations; }
+        }
+        if (trace) trace[(size_t)s * iters + i] = p;
+    }
+    pts[s] = p;
+}
+
+__global__ __launch_bounds__(RC_BLOCK) void k_get_delta_field(float* pt, size_t pt_step, const float* flow,
+                                                              size_t step, int w, int h, float dt, float UPPER_arg,
+                                                              const float* thr) {
+    const float UPPER = UPPER_arg < 0 ? thr[THR_UPPER] : UPPER_arg;
+    const long long total = (long long)w * h;
+    for (long long i = (long long)blockIdx.x * RC_BLOCK + threadIdx.x; i < total;
+         i += (long long)gridDim.x * RC_BLOCK) {
+        int yo = (int)(i / w), xo = (int)(i - (long long)yo * w);
+        float2* pp = (float2*)((char*)pt + (size_t)yo * pt_step) + xo;
+        float2 p = *pp;
+        float dx, dy;
+        if (!rc_sample_flow(flow, step, w, h, p.x + xo, p.y + yo, dx, dy)) continue;
+        float r = sqrtf(dx * dx + dy * dy);
+        if (r > UPPER) continue;
+        p.x = p.x + dx * dt;
+        p.y = p.y + dy * dt;
+        *pp = p;
+    }
+}
+
+// ============================================================================ B7 post-ops
+// Two-stage deterministic reductions: per-block partials in double, then one block folds
+// them in a fixed order.  part[b] = (sum x, sum y, sum |f|, max |f|)
+__device__ __forceinline__ double rc_wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float rc_wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(RC_BLOCK) void k_flow_stats_partial(const float* flow, size_t step, int x0, int y0,
+                                                                 int w, int h, double* part) {
+    double sx = 0, sy = 0, sm = 0;
+    float mx = 0.f;
+    const long long total = (long long)w * h;
+    for (long long i = (long long)blockIdx.x * RC_BLOCK + threadIdx.x; i < total;
+         i += (long long)gridDim.x * RC_BLOCK) {
+        int y = (int)(i / w), x = (int)(i - (long long)y * w);
+        float2 f = rc_row2(flow, step, y0 + y)[x0 + x];
+        float mag = sqrtf(f.x * f.x + f.y * f.y);
+        sx += f.x; sy += f.y; sm += mag;
+        mx = fmaxf(mx, mag);
+    }
+    __shared__ double sh[4][4];
+    sx = rc_wave_sum(sx); sy = rc_wave_sum(sy); sm = rc_wave_sum(sm); mx = rc_wave_max(mx);
+    int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[wv][0] = sx; sh[wv][1] = sy; sh[wv][2] = sm; sh[wv][3] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0, b = 0, c = 0, d = 0;
+        for (int k = 0; k < 4; k++) { a += sh[k][0]; b += sh[k][1]; c += sh[k][2]; d = fmax(d, sh[k][3]); }
+        part[4 * blockIdx.x] = a; part[4 * blockIdx.x + 1] = b; part[4 * blockIdx.x + 2] = c;
+        part[4 * blockIdx.x + 3] = d;
+    }
+}
+__global__ void k_flow_stats_final(const double* part, int nblocks, double* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double a = 0, b = 0, c = 0, d = 0;
+        for (int k = 0; k < nblocks; k++) {
+            a += part[4 * k]; b += part[4 * k + 1]; c += part[4 * k + 2]; d = fmax(d, part[4 * k + 3]);
+        }
+        out[0] = a; out[1] = b; out[2] = c; out[3] = d;
+    }
+}
+
+// mode 0: subtructAverage (:810-898); 1: subtructMeanMagnitude (:900-1015); 2: stabilizer (:300-307)
+__global__ __launch_bounds__(RC_BLOCK) void k_flow_postop(float* flow, size_t step, int w, int h, int mode,
+                                                          const double* stats, double divx, double divy) {
+    const long long total = (long long)w * h;
+    const double a0 = stats[0] / divx, a1 = stats[1] / divy;
+    const float meanval = (float)(stats[2] / ((double)w * h));
+    for (long long i = (long long)blockIdx.x * RC_BLOCK + threadIdx.x; i < total;
+         i += (long long)gridDim.x * RC_BLOCK) {
+        int y = (int)(i / w), x = (int)(i - (long long)y * w);
+        float2* pp = (float2*)((char*)flow + (size_t)y * step) + x;
+        float2 f = *pp;
+        if (mode == 0) {
+            f.x = (float)(f.x - a0);
+            f.y = (float)(f.y - a1);
+        } else if (mode == 1) {
+            float mag = sqrtf(f.x * f.x + f.y * f.y);
+            float ux, uy;
+            if (mag == 0) { ux = 0.f; uy = 0.f; }
+            else { ux = f.x / mag; uy = f.y / mag; }
+            f.x = ux * (mag - meanval);
+            f.y = uy * (mag - meanval);
+        } else {
+            if (f.x != 0) f.x = (float)(f.x - a0 * 0.2);
+            if (f.y != 0) f.y = (float)(f.y - a1 * 0.2);
+        }
+        *pp = f;
+    }
+}
+
+// main.cpp:1142-1153: avg -= slot/window; slot = cur; avg += slot/window
+__global__ void k_window_mean(float* avg, float* slot, const float* cur, size_t n, float inv) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float t = slot[i] * inv;
+        float a = avg[i] - t;
+        float c = cur[i];
+        slot[i] = c;
+        t = c * inv;
+        avg[i] = a + t;
+    }
+}
+
+// ============================================================================ B8 colouring
+// `uchar = float` as x86 compiles it: cvttss2si then the low byte (NaN/overflow -> INT_MIN).
+__device__ __forceinline__ uint8_t rc_f2u8(float v) {
+    int iv;
+    if (!(v > -2147483904.f && v < 2147483648.f)) iv = INT_MIN;
+    else iv = (int)v;
+    return (uint8_t)(iv & 0xFF);
+}
+
+__global__ __launch_bounds__(RC_BLOCK) void k_vector_to_color(const float* flow, size_t step, int w, int h,
+                                                              uint8_t* hsv, size_t hsv_step, float max_disp) {
+    const long long total = (long long)w * h;
+    for (long long i = (long long)blockIdx.x * RC_BLOCK + threadIdx.x; i < total;
+         i += (long long)gridDim.x * RC_BLOCK) {
+        int y = (int)(i / w), x = (int)(i - (long long)y * w);
+        float2 f = rc_row2(flow, step, y)[x];
+        float theta = (float)(atan2f(f.y, f.x) * 180 / 3.14159265358979323846);
+        theta += theta < 0 ? 360 : 0;
+        float mag = sqrtf(f.x * f.x + f.y * f.y);
+        uint8_t* q = hsv + (size_t)y * hsv_step + 3 * x;
+        q[0] = rc_f2u8(theta / 2);
+        q[1] = 255;
+        q[2] = rc_f2u8(mag * 255 / max_disp);
+    }
+}
+
+__global__ __launch_bounds__(RC_BLOCK) void k_shear_to_color(const float* flow, size_t step, int w, int h,
+                                                             uint8_t* hsv, size_t hsv_step, float max_fro,
+                                                             float* part_max) {
+    const int off = 10;
+    const int iw = w - 2 * off, ih = h - 2 * off;
+    float mx = 0.f;
+    const long long total = (long long)iw * ih;
+    for (long long i = (long long)blockIdx.x * RC_BLOCK + threadIdx.x; i < total;
+         i += (long long)gridDim.x * RC_BLOCK) {
+        int row = off + (int)(i / iw), col = off + (int)(i % iw);
+        float2 above = rc_row2(flow, step, row - off)[col], below = rc_row2(flow, step, row + off)[col];
+        float2 left = rc_row2(flow, step, row)[col - off], right = rc_row2(flow, step, row)[col + off];
+        float j00 = right.x - left.x, j01 = above.x - below.x;
+        float j10 = right.y - left.y, j11 = above.y - below.y;
+        float fro = j00 * j00 + j01 * j01 + j10 * j10 + j11 * j11;
+        fro = sqrtf(fro);
+        uint8_t* q = hsv + (size_t)row * hsv_step + 3 * col;
+        q[0] = rc_f2u8(128 - fro * 128 / max_fro);
+        q[1] = 255;
+        q[2] = 255;
+        mx = fmaxf(mx, fro);
+    }
+    __shared__ float sh[4];
+    mx = rc_wave_max(mx);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) part_max[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+// ============================================================================ host side
+static int grid_for(long long items) {
+    long long b = (items + RC_BLOCK - 1) / RC_BLOCK;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));   // memory-bound: cap and grid-stride
+}
+
+static int analysis_ensure(rc_ctx* ctx, RcSlot& s, int w, int h, bool reset) {
+    if (w <= 0 || h <= 0) return RC_EINVAL;
+    if (w > ctx->max_w || h > ctx->max_h) { rc_set_error("frame exceeds the context size"); return RC_ESIZE; }
+    RcAnalysis& an = s.an;
+    bool fresh = (an.w != w || an.h != h || !an.hist.p);
+    if (!fresh && !reset) return RC_OK;
+    size_t n = (size_t)w * h;
+    int rc;
+    if ((rc = rc_buf_ensure(an.hist, RC_HIST_WORDS * sizeof(int)))) return rc;
+    if ((rc = rc_buf_ensure(an.thr, (THR_WORDS + 3) * sizeof(float)))) return rc;
+    if ((rc = rc_buf_ensure(an.acc, n * sizeof(float)))) return rc;
+    if ((rc = rc_buf_ensure(an.pt, n * sizeof(float2)))) return rc;
+    if ((rc = rc_buf_ensure(an.dist, n * sizeof(float)))) return rc;
+    if ((rc = rc_buf_ensure(an.scratch, (4 * 2048 + 8) * sizeof(double)))) return rc;
+    an.w = w; an.h = h;
+    RC_HIP(hipMemsetAsync(an.hist.p, 0, RC_HIST_WORDS * sizeof(int), s.cur));
+    RC_HIP(hipMemsetAsync(an.acc.p, 0, n * sizeof(float), s.cur));
+    RC_HIP(hipMemsetAsync(an.pt.p, 0, n * sizeof(float2), s.cur));
+    RC_HIP(hipMemsetAsync(an.dist.p, 0, n * sizeof(float), s.cur));
+    // UPPER = 100.0, UPPER2d = prop_above_upper = 0 (ripcurrents.cpp:149-154)
+    float init[THR_WORDS] = {0};
+    init[THR_UPPER] = 100.0f;
+    RC_HIP(hipMemcpyAsync(an.thr.p, init, sizeof(init), hipMemcpyHostToDevice, s.cur));
+    RC_HIP(hipStreamSynchronize(s.cur));
+    return RC_OK;
+}
+
+extern "C" int rcflow_analysis_reset(rc_ctx* ctx, int stream, int w, int h) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    RC_HIP(hipSetDevice(ctx->device));
+    return analysis_ensure(ctx, *s, w, h, true);
+}
+
+static int check_flow(const float* d_flow, size_t step, int w, int h) {
+    if (!d_flow || w <= 0 || h <= 0 || step < (size_t)w * 8 || (step & 7)) {
+        rc_set_error("bad flow field argument");
+        return RC_EINVAL;
+    }
+    return RC_OK;
+}
+
+extern "C" int rcflow_histogram_dev(rc_ctx* ctx, int stream, const float* d_flow, size_t flow_step, int w, int h) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    int rc = check_flow(d_flow, flow_step, w, h);
+    if (rc) return rc;
+    RC_HIP(hipSetDevice(ctx->device));
+    if ((rc = analysis_ensure(ctx, *s, w, h, false))) return rc;
+    {
+        RcProfScope ps(ctx, s->cur, RC_K_HIST, 0, 8. * w * h);
+        hipLaunchKernelGGL(k_polar_hist, dim3(grid_for(((long long)(w + 1) / 2) * h)), dim3(RC_BLOCK), 0, s->cur,
+                           d_flow, flow_step, w, h, (int*)s->an.hist.p);
+    }
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+extern "C" int rcflow_thresholds_dev(rc_ctx* ctx, int stream) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    if (!s->an.hist.p) { rc_set_error("no histogram state: call rcflow_analysis_reset first"); return RC_ESTATE; }
+    RC_HIP(hipSetDevice(ctx->device));
+    {
+        RcProfScope ps(ctx, s->cur, RC_K_THRESH, 0, 4. * RC_HIST_WORDS);
+        hipLaunchKernelGGL(k_thresholds, dim3(1), dim3(64), 0, s->cur, (const int*)s->an.hist.p, (float*)s->an.thr.p);
+    }
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+extern "C" int rcflow_histogram_read(rc_ctx* ctx, int stream, int32_t* hist, int32_t* hist2d, int32_t* histsum,
+                                     int32_t* histsum2d, float* UPPER, float* UPPER2d, float* prop) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    if (!s->an.hist.p) { rc_set_error("no histogram state"); return RC_ESTATE; }
+    RC_HIP(hipSetDevice(ctx->device));
+    int32_t words[RC_HIST_WORDS];
+    float thr[THR_WORDS];
+    RC_HIP(hipMemcpyAsync(words, s->an.hist.p, sizeof(words), hipMemcpyDeviceToHost, s->cur));
+    RC_HIP(hipMemcpyAsync(thr, s->an.thr.p, sizeof(thr), hipMemcpyDeviceToHost, s->cur));
+    RC_HIP(hipStreamSynchronize(s->cur));
+    if (hist) memcpy(hist, words, RC_HIST_BINS * 4);
+    if (hist2d) memcpy(hist2d, words + RC_HIST_BINS, RC_HIST_DIRECTIONS * RC_HIST_BINS * 4);
+    if (histsum) *histsum = words[RC_HIST_BINS + RC_HIST_DIRECTIONS * RC_HIST_BINS];
+    if (histsum2d) memcpy(histsum2d, words + RC_HIST_BINS + RC_HIST_DIRECTIONS * RC_HIST_BINS + 1, RC_HIST_DIRECTIONS * 4);
+    if (UPPER) *UPPER = thr[THR_UPPER];
+    if (UPPER2d) memcpy(UPPER2d, thr + THR_UPPER2D, RC_HIST_DIRECTIONS * 4);
+    if (prop) memcpy(prop, thr + THR_PROP, RC_HIST_DIRECTIONS * 4);
+    return RC_OK;
+}
+
+extern "C" int rcflow_histogram_write(rc_ctx* ctx, int stream, const int32_t* words) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !words) return RC_EINVAL;
+    if (!s->an.hist.p) { rc_set_error("no histogram state"); return RC_ESTATE; }
+    RC_HIP(hipSetDevice(ctx->device));
+    RC_HIP(hipMemcpyAsync(s->an.hist.p, words, RC_HIST_WORDS * 4, hipMemcpyHostToDevice, s->cur));
+    RC_HIP(hipStreamSynchronize(s->cur));
+    return RC_OK;
+}
+
+extern "C" int rcflow_histogram_device_ptr(rc_ctx* ctx, int stream, int32_t** d_words) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !d_words) return RC_EINVAL;
+    if (!s->an.hist.p) { rc_set_error("no histogram state"); return RC_ESTATE; }
+    *d_words = (int32_t*)s->an.hist.p;
+    return RC_OK;
+}
+
+extern "C" int rcflow_classify_accumulate_dev(rc_ctx* ctx, int stream, const float* d_flow, size_t flow_step,
+                                              int w, int h, int framecount, float MID, float LOWER,
+                                              float* d_polar, size_t polar_step, float* d_wclass, size_t wc_step,
+                                              float* d_out, size_t out_step, uint8_t* d_mask, size_t mask_step) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    int rc = check_flow(d_flow, flow_step, w, h);
+    if (rc) return rc;
+    if ((d_polar && polar_step < (size_t)w * 12) || (d_wclass && wc_step < (size_t)w * 12) ||
+        (d_out && out_step < (size_t)w * 12) || (d_mask && mask_step < (size_t)w)) {
+        rc_set_error("output step smaller than a row");
+        return RC_EINVAL;
+    }
+    RC_HIP(hipSetDevice(ctx->device));
+    if ((rc = analysis_ensure(ctx, *s, w, h, false))) return rc;
+    ClassifyArgs a = {d_flow, flow_step, w, h, framecount, MID, LOWER, (const float*)s->an.thr.p,
+                      (float*)s->an.acc.p, d_polar, polar_step, d_wclass, wc_step, d_out, out_step, d_mask, mask_step};
+    {
+        RcProfScope ps(ctx, s->cur, RC_K_CLASSIFY, 0, 16. * w * h);
+        hipLaunchKernelGGL(k_classify_accumulate, dim3(grid_for((long long)w * h)), dim3(RC_BLOCK), 0, s->cur, a);
+    }
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+extern "C" int rcflow_accumulator_read(rc_ctx* ctx, int stream, float* acc) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !acc) return RC_EINVAL;
+    if (!s->an.acc.p) { rc_set_error("no analysis state"); return RC_ESTATE; }
+    RC_HIP(hipSetDevice(ctx->device));
+    RC_HIP(hipMemcpyAsync(acc, s->an.acc.p, (size_t)s->an.w * s->an.h * 4, hipMemcpyDeviceToHost, s->cur));
+    RC_HIP(hipStreamSynchronize(s->cur));
+    return RC_OK;
+}
+
+extern "C" int rcflow_advect_field_dev(rc_ctx* ctx, int stream, const float* d_flow, size_t flow_step, int w, int h,
+                                       float dt, int iterations, float UPPER) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    int rc = check_flow(d_flow, flow_step, w, h);
+    if (rc) return rc;
+    if (iterations < 0) return RC_EINVAL;
+    RC_HIP(hipSetDevice(ctx->device));
+    if ((rc = analysis_ensure(ctx, *s, w, h, false))) return rc;
+    {
+        RcProfScope ps(ctx, s->cur, RC_K_ADVECT_FIELD, 0, 32. * w * h);
+        hipLaunchKernelGGL(k_advect_field, dim3(grid_for((long long)w * h)), dim3(RC_BLOCK), 0, s->cur,
+                           (float2*)s->an.pt.p, (float*)s->an.dist.p, d_flow, flow_step, w, h, dt, iterations, UPPER,
+                           (const float*)s->an.thr.p);
+    }
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+extern "C" int rcflow_advect_field_read(rc_ctx* ctx, int stream, float* pt_xy, float* dist) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    if (!s->an.pt.p) { rc_set_error("no analysis state"); return RC_ESTATE; }
+    RC_HIP(hipSetDevice(ctx->device));
+    size_t n = (size_t)s->an.w * s->an.h;
+    if (pt_xy) RC_HIP(hipMemcpyAsync(pt_xy, s->an.pt.p, n * 8, hipMemcpyDeviceToHost, s->cur));
+    if (dist) RC_HIP(hipMemcpyAsync(dist, s->an.dist.p, n * 4, hipMemcpyDeviceToHost, s->cur));
+    RC_HIP(hipStreamSynchronize(s->cur));
+    return RC_OK;
+}
+
+static int thr_ptr(rc_ctx* ctx, RcSlot& s, float UPPER, const float** thr) {
+    *thr = (const float*)s.an.thr.p;
+    if (UPPER < 0 && !s.an.thr.p) { rc_set_error("UPPER<0 needs the slot's analysis state"); return RC_ESTATE; }
+    (void)ctx;
+    return RC_OK;
+}
+
+extern "C" int rcflow_advect_points_dev(rc_ctx* ctx, int stream, float* d_pts, int n, const float* d_flow,
+                                        size_t flow_step, int w, int h, float dt, int iterations, float UPPER,
+                                        int variant, float* d_trace) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    int rc = check_flow(d_flow, flow_step, w, h);
+    if (rc) return rc;
+    if (n < 0 || (n && !d_pts) || iterations < 0 || variant < 0 || variant > 4) return RC_EINVAL;
+    if (n == 0) return RC_OK;
+    RC_HIP(hipSetDevice(ctx->device));
+    const float* thr;
+    if ((rc = thr_ptr(ctx, *s, UPPER, &thr))) return rc;
+    {
+        RcProfScope ps(ctx, s->cur, RC_K_ADVECT_POINTS, 0, 16. * n);
+        hipLaunchKernelGGL(k_advect_points, dim3((n + 63) / 64), dim3(64), 0, s->cur, (float2*)d_pts, n, d_flow,
+                           flow_step, w, h, dt, iterations, UPPER, thr, variant, (float2*)d_trace);
+    }
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+extern "C" int rcflow_get_delta_field_dev(rc_ctx* ctx, int stream, float* d_pt, size_t pt_step, const float* d_flow,
+                                          size_t flow_step, int w, int h, float dt, float UPPER) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    int rc = check_flow(d_flow, flow_step, w, h);
+    if (rc) return rc;
+    if (!d_pt || pt_step < (size_t)w * 8) return RC_EINVAL;
+    RC_HIP(hipSetDevice(ctx->device));
+    const float* thr;
+    if ((rc = thr_ptr(ctx, *s, UPPER, &thr))) return rc;
+    hipLaunchKernelGGL(k_get_delta_field, dim3(grid_for((long long)w * h)), dim3(RC_BLOCK), 0, s->cur, d_pt, pt_step,
+                       d_flow, flow_step, w, h, dt, UPPER, thr);
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+// stats of a sub-rectangle into scratch[4*2048 .. +4): sum x, sum y, sum |f|, max |f|
+static int flow_stats(rc_ctx* ctx, RcSlot& s, const float* d_flow, size_t step, int x0, int y0, int w, int h) {
+    int rc = rc_buf_ensure(s.an.scratch, (4 * 2048 + 8) * sizeof(double));
+    if (rc) return rc;
+    double* part = (double*)s.an.scratch.p;
+    int nb = grid_for((long long)w * h);
+    hipLaunchKernelGGL(k_flow_stats_partial, dim3(nb), dim3(RC_BLOCK), 0, s.cur, d_flow, step, x0, y0, w, h, part);
+    hipLaunchKernelGGL(k_flow_stats_final, dim3(1), dim3(64), 0, s.cur, part, nb, part + 4 * 2048);
+    (void)ctx;
+    return RC_OK;
+}
+
+static int postop(rc_ctx* ctx, int stream, float* d_flow, size_t step, int w, int h, int mode) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    int rc = check_flow(d_flow, step, w, h);
+    if (rc) return rc;
+    RC_HIP(hipSetDevice(ctx->device));
+    double divx = (double)w * h, divy = (double)w * h;
+    RcProfScope ps(ctx, s->cur, RC_K_POSTOP, mode, 24. * w * h);
+    if (mode == 2) {
+        // patch = last 10% of rows and columns; the reference divides sum_x by the patch's
+        // column count and sum_y by its row count (ripcurrents_module.cpp:295-296)
+        int x0 = (int)(w * 0.9), y0 = (int)(h * 0.9);
+        divx = w - x0;
+        divy = h - y0;
+        if ((rc = flow_stats(ctx, *s, d_flow, step, x0, y0, w - x0, h - y0))) return rc;
+    } else {
+        if ((rc = flow_stats(ctx, *s, d_flow, step, 0, 0, w, h))) return rc;
+    }
+    hipLaunchKernelGGL(k_flow_postop, dim3(grid_for((long long)w * h)), dim3(RC_BLOCK), 0, s->cur, d_flow, step, w, h,
+                       mode, (const double*)s->an.scratch.p + 4 * 2048, divx, divy);
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+extern "C" int rcflow_subtract_average_dev(rc_ctx* ctx, int stream, float* d_flow, size_t step, int w, int h) {
+    return postop(ctx, stream, d_flow, step, w, h, 0);
+}
+extern "C" int rcflow_subtract_mean_magnitude_dev(rc_ctx* ctx, int stream, float* d_flow, size_t step, int w, int h) {
+    return postop(ctx, stream, d_flow, step, w, h, 1);
+}
+extern "C" int rcflow_stabilizer_dev(rc_ctx* ctx, int stream, float* d_flow, size_t step, int w, int h) {
+    return postop(ctx, stream, d_flow, step, w, h, 2);
+}
+
+extern "C" int rcflow_window_mean_dev(rc_ctx* ctx, int stream, float* d_avg, float* d_slot, const float* d_cur,
+                                      size_t n, int window) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !d_avg || !d_slot || !d_cur || window < 1) return RC_EINVAL;
+    RC_HIP(hipSetDevice(ctx->device));
+    float inv = (float)(1. / (float)window);
+    hipLaunchKernelGGL(k_window_mean, dim3(grid_for((long long)n)), dim3(RC_BLOCK), 0, s->cur, d_avg, d_slot, d_cur, n, inv);
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+extern "C" int rcflow_vector_to_color_dev(rc_ctx* ctx, int stream, const float* d_flow, size_t step, int w, int h,
+                                          uint8_t* d_hsv, size_t hsv_step, float* max_io) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    int rc = check_flow(d_flow, step, w, h);
+    if (rc) return rc;
+    if (!d_hsv || hsv_step < (size_t)w * 3 || !max_io) return RC_EINVAL;
+    RC_HIP(hipSetDevice(ctx->device));
+    if ((rc = flow_stats(ctx, *s, d_flow, step, 0, 0, w, h))) return rc;
+    {
+        RcProfScope ps(ctx, s->cur, RC_K_COLOR, 0, 11. * w * h);
+        hipLaunchKernelGGL(k_vector_to_color, dim3(grid_for((long long)w * h)), dim3(RC_BLOCK), 0, s->cur, d_flow, step,
+                           w, h, d_hsv, hsv_step, *max_io);
+    }
+    double st[4];
+    RC_HIP(hipMemcpyAsync(st, (const double*)s->an.scratch.p + 4 * 2048, sizeof(st), hipMemcpyDeviceToHost, s->cur));
+    RC_HIP(hipStreamSynchronize(s->cur));
+    *max_io = (float)st[3];
+    return RC_OK;
+}
+
+extern "C" int rcflow_shear_rate_to_color_dev(rc_ctx* ctx, int stream, const float* d_flow, size_t step, int w, int h,
+                                              uint8_t* d_hsv, size_t hsv_step, float* max_io) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    int rc = check_flow(d_flow, step, w, h);
+    if (rc) return rc;
+    if (!d_hsv || hsv_step < (size_t)w * 3 || !max_io) return RC_EINVAL;
+    if (w <= 20 || h <= 20) { *max_io = 0.f; return RC_OK; }
+    RC_HIP(hipSetDevice(ctx->device));
+    if ((rc = rc_buf_ensure(s->an.scratch, (4 * 2048 + 8) * sizeof(double)))) return rc;
+    int nb = grid_for((long long)(w - 20) * (h - 20));
+    float* part = (float*)s->an.scratch.p;
+    {
+        RcProfScope ps(ctx, s->cur, RC_K_COLOR, 1, 11. * w * h);
+        hipLaunchKernelGGL(k_shear_to_color, dim3(nb), dim3(RC_BLOCK), 0, s->cur, d_flow, step, w, h, d_hsv, hsv_step,
+                           *max_io, part);
+    }
+    std::vector<float> hp(nb);
+    RC_HIP(hipMemcpyAsync(hp.data(), part, nb * sizeof(float), hipMemcpyDeviceToHost, s->cur));
+    RC_HIP(hipStreamSynchronize(s->cur));
+    float mx = 0.f;
+    for (float v : hp) mx = v > mx ? v : mx;
+    *max_io = mx;
+    return RC_OK;
+}

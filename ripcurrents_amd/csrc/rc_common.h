@@ -1,0 +1,103 @@
+// rc_common.h -- shared declarations of the HIP implementation (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rcflow.h"
+
+#define RC_MAX_LEVELS 12
+#define RC_MAX_POLY_N 32      // taps -n..n kept on device
+#define RC_MAX_WIN_M 32       // window radius winsize/2
+
+// Built with -ffp-contract=off: a*b+c rounds twice unless written as fmaf().
+#define RC_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+
+// Geometry and constants of one pyramid scale.
+struct RcLevel {
+    int w, h;            // level size (cvRound(W*scale))
+    double scale_x;      // W0 / w   (resize.cpp scale_x)
+    double scale_y;
+    double sigma;        // pyramid blur sigma
+    int ksize;           // pyramid blur taps
+    int pyr_tw, pyr_th;  // pyr_level tile
+    int pyr_reg_w, pyr_reg_h;  // LDS source region bounds (bytes / rows)
+    size_t pyr_lds;
+};
+
+// Polynomial-expansion constants (FarnebackPrepareGaussian), taps 0..n.
+struct RcPolyK {
+    float g[RC_MAX_POLY_N + 1];
+    float xg[RC_MAX_POLY_N + 1];
+    float xxg[RC_MAX_POLY_N + 1];
+    double ig11, ig03, ig33, ig55;
+    double kdc;   // coefficient of the removed DC term in the yy/xx outputs
+    int n;        // requested radius
+    int n_eff;    // radius actually evaluated
+};
+
+// Window of FarnebackUpdateFlow_*: box (scale = 1/bs^2) or Gaussian (float taps).
+struct RcWindow {
+    float k[RC_MAX_WIN_M + 1];
+    double box_scale;
+    int m;
+    int gaussian;
+};
+
+struct RcPyrArgs {
+    const uint8_t* src;       // frame 0
+    size_t src_step;          // bytes per row
+    size_t src_frame_stride;  // bytes per frame
+    int W0, H0;
+    float* dst;               // I_k slot base
+    size_t dst_slot_stride;   // floats per slot
+    int dslot0, nslots;       // destination slot of frame z is (dslot0+z)%nslots
+    int w, h;
+    double scale_x, scale_y;
+    int ksize;
+    const float* kern;        // device, ksize floats
+    int tw, th, reg_wp, reg_hmax;
+};
+
+struct RcPolyArgs {
+    const float* I;           // I_k slot base
+    size_t I_slot_stride;
+    float4* RA;               // (y, x, yy, xx) coefficients
+    float* RB;                // xy coefficient
+    size_t R_slot_stride;     // elements per slot (pixels)
+    int slot0, nslots;
+    int w, h;
+    RcPolyK pk;
+};
+
+struct RcIterArgs {
+    const float4* RA;         // R slot base of this level
+    const float* RB;
+    size_t R_slot_stride;
+    int slot0, slot1, nslots; // pair z uses slots (slot0+z)%n and (slot1+z)%n
+    int w, h;
+    // flow in: mode 0 zeros, 1 same-resolution, 2 coarser level (resize * mul)
+    int in_mode;
+    const float2* fin;
+    size_t fin_pair_stride;   // elements
+    int fin_w, fin_h;
+    double up_scale_x, up_scale_y;
+    float up_mul;
+    // flow out
+    char* fout;
+    size_t fout_step;         // bytes per row
+    size_t fout_pair_stride;  // bytes per pair
+    int tw, th;               // tile
+    int tiles_x, tiles_y;
+    int solve;                // 0: write flow_in (iterations == 0), 1: normal
+    RcWindow win;
+};
+
+void rc_launch_pyr(const RcPyrArgs& a, int frames, size_t lds, hipStream_t s);
+void rc_launch_polyexp(const RcPolyArgs& a, int frames, hipStream_t s);
+void rc_launch_flow_iter(const RcIterArgs& a, int pairs, hipStream_t s);
+size_t rc_flow_iter_lds(int tw, int th, int m);
+
+// interleave helpers for the stage-level test entry points
+void rc_launch_pack_R5(const float* R5, float4* RA, float* RB, int n, hipStream_t s);
+void rc_launch_unpack_R5(const float4* RA, const float* RB, float* R5, int n, hipStream_t s);

@@ -1,0 +1,94 @@
+// rc_host.h -- host-side context, plans and stream slots of librcflow (internal).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "rc_common.h"
+
+struct RcBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct RcPlan {
+    bool valid = false;
+    int w = 0, h = 0;
+    rc_farneback_params prm{};
+    int nlev = 0;  // number of scales = cropped levels + 1
+    RcLevel lv[RC_MAX_LEVELS];
+    size_t kern_off[RC_MAX_LEVELS];
+    RcPolyK pk;
+    RcWindow win;
+    int iter_tw = 64, iter_th = 16;
+    int nslots = 0, chunk = 0;
+    int exact_taps = 0;
+};
+
+// Device-resident analysis state of one stream slot (ripcurrents.cpp:133-176).
+struct RcAnalysis {
+    int w = 0, h = 0;
+    RcBuf hist;        // RC_HIST_WORDS int32
+    RcBuf thr;         // UPPER | UPPER2d[36] | prop[36] floats (+1 pad)
+    RcBuf acc;         // h*w float accumulator (.x channel of the reference's 32FC3)
+    RcBuf pt;          // h*w float2 streamlines_mat
+    RcBuf dist;        // h*w float streamlines_distance
+    RcBuf scratch;     // reductions
+};
+
+struct RcSlot {
+    hipStream_t own = nullptr, cur = nullptr;
+    RcPlan plan;
+    RcBuf kern;
+    RcBuf I[RC_MAX_LEVELS], RA[RC_MAX_LEVELS], RB[RC_MAX_LEVELS];
+    RcBuf FA[RC_MAX_LEVELS], FB[RC_MAX_LEVELS];
+    RcBuf stage_u8, stage_flow, stage_f32[4];
+    int primed = 0, cur_slot = 0;
+    RcAnalysis an;
+};
+
+struct RcProfRec {
+    int id;
+    hipEvent_t e0, e1;
+    double bytes;
+};
+
+struct rc_ctx {
+    int device = 0;
+    int max_w = 0, max_h = 0, nstreams = 0;
+    RcSlot* slots = nullptr;
+    int chunk = 4;
+    int exact_taps = 0;
+    int prof_on = 0;
+    std::vector<RcProfRec> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> prof_launches;
+    std::vector<double> prof_ms, prof_bytes;
+};
+
+enum { RC_K_PYR = 0, RC_K_POLY = 1, RC_K_ITER = 2, RC_K_HIST = 3, RC_K_THRESH = 4, RC_K_CLASSIFY = 5,
+       RC_K_ADVECT_FIELD = 6, RC_K_ADVECT_POINTS = 7, RC_K_POSTOP = 8, RC_K_COLOR = 9, RC_K_KINDS = 10 };
+
+void rc_set_error(const char* fmt, ...);
+int rc_buf_ensure(RcBuf& b, size_t bytes);
+void rc_buf_free(RcBuf& b);
+RcSlot* rc_slot(rc_ctx* ctx, int stream);
+
+struct RcProfScope {
+    rc_ctx* ctx;
+    hipStream_t s;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int id;
+    double bytes;
+    RcProfScope(rc_ctx* c, hipStream_t st, int kind, int level, double alg_bytes);
+    ~RcProfScope();
+};
+
+#define RC_HIP(call)                                                                  \
+    do {                                                                              \
+        hipError_t e_ = (call);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            rc_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return RC_EHIP;                                                           \
+        }                                                                             \
+    } while (0)

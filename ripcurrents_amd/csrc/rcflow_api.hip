@@ -1,0 +1,757 @@
+// rcflow_api.hip -- C ABI of librcflow.so: context, plans, level driver (A7) and the
+// Farneback entry points.  See include/rcflow.h for the reference interfaces replaced.
+
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "rc_host.h"
+
+// ---------------------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+void rc_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* rcflow_last_error(void) { return g_err; }
+extern "C" int rcflow_abi_version(void) { return RCFLOW_ABI_VERSION; }
+
+int rc_buf_ensure(RcBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return RC_OK;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+    if (bytes == 0) return RC_OK;
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) {
+        rc_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        b.p = nullptr;
+        return RC_ENOMEM;
+    }
+    b.bytes = bytes;
+    return RC_OK;
+}
+void rc_buf_free(RcBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+RcSlot* rc_slot(rc_ctx* ctx, int stream) {
+    if (!ctx || stream < 0 || stream >= ctx->nstreams) {
+        rc_set_error("bad context or stream index %d", stream);
+        return nullptr;
+    }
+    return &ctx->slots[stream];
+}
+
+// ---------------------------------------------------------------------------- profiling
+RcProfScope::RcProfScope(rc_ctx* c, hipStream_t st, int kind, int level, double alg_bytes)
+    : ctx(c), s(st), id(kind * RC_MAX_LEVELS + level), bytes(alg_bytes) {
+    if (!ctx->prof_on) return;
+    for (int i = 0; i < 2; i++) {
+        hipEvent_t e;
+        if (!ctx->ev_pool.empty()) {
+            e = ctx->ev_pool.back();
+            ctx->ev_pool.pop_back();
+        } else if (hipEventCreate(&e) != hipSuccess) {
+            e = nullptr;
+        }
+        (i ? e1 : e0) = e;
+    }
+    if (e0) (void)hipEventRecord(e0, s);
+}
+RcProfScope::~RcProfScope() {
+    if (!ctx->prof_on || !e0 || !e1) return;
+    (void)hipEventRecord(e1, s);
+    ctx->prof_pending.push_back({id, e0, e1, bytes});
+}
+
+static const char* kKindNames[RC_K_KINDS] = {"pyr_level", "polyexp", "flow_iter", "polar_hist",
+                                             "thresholds", "classify_accumulate", "advect_field",
+                                             "advect_points", "flow_postop", "flow_color"};
+static char g_names[RC_K_KINDS * RC_MAX_LEVELS][40];
+
+static void prof_resolve(rc_ctx* ctx) {
+    size_t n = RC_K_KINDS * RC_MAX_LEVELS;
+    if (ctx->prof_ms.size() != n) {
+        ctx->prof_ms.assign(n, 0.);
+        ctx->prof_bytes.assign(n, 0.);
+        ctx->prof_launches.assign(n, 0);
+    }
+    for (auto& r : ctx->prof_pending) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(r.e1);
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            ctx->prof_ms[r.id] += ms;
+            ctx->prof_bytes[r.id] += r.bytes;
+            ctx->prof_launches[r.id]++;
+        }
+        ctx->ev_pool.push_back(r.e0);
+        ctx->ev_pool.push_back(r.e1);
+    }
+    ctx->prof_pending.clear();
+}
+
+extern "C" int rcflow_profile_enable(rc_ctx* ctx, int on) {
+    if (!ctx) return RC_EINVAL;
+    if (!on) prof_resolve(ctx);
+    ctx->prof_on = on ? 1 : 0;
+    return RC_OK;
+}
+extern "C" int rcflow_profile_reset(rc_ctx* ctx) {
+    if (!ctx) return RC_EINVAL;
+    prof_resolve(ctx);
+    ctx->prof_ms.assign(ctx->prof_ms.size(), 0.);
+    ctx->prof_bytes.assign(ctx->prof_bytes.size(), 0.);
+    ctx->prof_launches.assign(ctx->prof_launches.size(), 0);
+    return RC_OK;
+}
+extern "C" int rcflow_profile_read(rc_ctx* ctx, int cap, const char** names, int* launches,
+                                   double* total_ms, double* alg_bytes) {
+    if (!ctx) return RC_EINVAL;
+    prof_resolve(ctx);
+    int n = 0;
+    for (size_t id = 0; id < ctx->prof_ms.size() && n < cap; id++) {
+        if (!ctx->prof_launches[id]) continue;
+        snprintf(g_names[id], sizeof(g_names[id]), "%s@%d", kKindNames[id / RC_MAX_LEVELS],
+                 (int)(id % RC_MAX_LEVELS));
+        if (names) names[n] = g_names[id];
+        if (launches) launches[n] = ctx->prof_launches[id];
+        if (total_ms) total_ms[n] = ctx->prof_ms[id];
+        if (alg_bytes) alg_bytes[n] = ctx->prof_bytes[id];
+        n++;
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------- lifetime
+extern "C" int rcflow_create(rc_ctx** out, int device, int max_w, int max_h, int max_streams) {
+    if (!out || max_w <= 0 || max_h <= 0 || max_streams <= 0 || max_streams > 256) {
+        rc_set_error("rcflow_create: bad arguments");
+        return RC_EINVAL;
+    }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        rc_set_error("rcflow_create: no usable HIP device (count=%d, requested %d)", ndev, device);
+        return RC_ENODEV;
+    }
+    RC_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    RC_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        rc_set_error("rcflow_create: device %d is %s; this library holds gfx950 code only", device,
+                     prop.gcnArchName);
+        return RC_ENODEV;
+    }
+    rc_ctx* ctx = new rc_ctx();
+    ctx->device = device;
+    ctx->max_w = max_w;
+    ctx->max_h = max_h;
+    ctx->nstreams = max_streams;
+    ctx->slots = new RcSlot[max_streams];
+    for (int i = 0; i < max_streams; i++) {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->slots[i].own, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            rc_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            rcflow_destroy(ctx);
+            return RC_EHIP;
+        }
+        ctx->slots[i].cur = ctx->slots[i].own;
+    }
+    *out = ctx;
+    return RC_OK;
+}
+
+static void slot_free(RcSlot& s) {
+    rc_buf_free(s.kern);
+    for (int k = 0; k < RC_MAX_LEVELS; k++) {
+        rc_buf_free(s.I[k]); rc_buf_free(s.RA[k]); rc_buf_free(s.RB[k]);
+        rc_buf_free(s.FA[k]); rc_buf_free(s.FB[k]);
+    }
+    rc_buf_free(s.stage_u8); rc_buf_free(s.stage_flow);
+    for (auto& b : s.stage_f32) rc_buf_free(b);
+    rc_buf_free(s.an.hist); rc_buf_free(s.an.thr); rc_buf_free(s.an.acc);
+    rc_buf_free(s.an.pt); rc_buf_free(s.an.dist); rc_buf_free(s.an.scratch);
+    if (s.own) (void)hipStreamDestroy(s.own);
+    s.own = s.cur = nullptr;
+}
+
+extern "C" void rcflow_destroy(rc_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    prof_resolve(ctx);
+    for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->slots) {
+        for (int i = 0; i < ctx->nstreams; i++) slot_free(ctx->slots[i]);
+        delete[] ctx->slots;
+    }
+    delete ctx;
+}
+
+extern "C" int rcflow_sync(rc_ctx* ctx, int stream) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    RC_HIP(hipStreamSynchronize(s->cur));
+    return RC_OK;
+}
+
+extern "C" int rcflow_set_hip_stream(rc_ctx* ctx, int stream, void* hip_stream) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    s->cur = hip_stream ? (hipStream_t)hip_stream : s->own;
+    return RC_OK;
+}
+
+extern "C" int rcflow_set_option(rc_ctx* ctx, const char* name, int value) {
+    if (!ctx || !name) return RC_EINVAL;
+    if (!strcmp(name, "chunk")) {
+        if (value < 1 || value > 64) return RC_EINVAL;
+        ctx->chunk = value;
+    } else if (!strcmp(name, "exact_taps")) {
+        ctx->exact_taps = value ? 1 : 0;
+    } else {
+        rc_set_error("unknown option %s", name);
+        return RC_EINVAL;
+    }
+    for (int i = 0; i < ctx->nstreams; i++) ctx->slots[i].plan.valid = false;
+    return RC_OK;
+}
+
+// ---------------------------------------------------------------------------- plan (A7 geometry)
+static inline int cv_round(double v) { return (int)nearbyint(v); }   // round half to even
+
+static int crop_levels(int w, int h, double pyr_scale, int levels) {
+    const int min_size = 32;   // optflow.cpp calc()
+    int k;
+    double scale = 1;
+    for (k = 0; k < levels; k++) {
+        scale *= pyr_scale;
+        if (w * scale < min_size || h * scale < min_size) break;
+    }
+    return k;
+}
+
+static void level_geom(int w, int h, double pyr_scale, int k, RcLevel& L) {
+    double scale = 1;
+    for (int i = 0; i < k; i++) scale *= pyr_scale;
+    L.sigma = (1. / scale - 1) * 0.5;
+    int smooth_sz = cv_round(L.sigma * 5) | 1;
+    L.ksize = smooth_sz > 3 ? smooth_sz : 3;
+    L.w = cv_round(w * scale);
+    L.h = cv_round(h * scale);
+    L.scale_x = 1. / ((double)L.w / w);
+    L.scale_y = 1. / ((double)L.h / h);
+}
+
+extern "C" int rcflow_level_geometry(int w, int h, double pyr_scale, int levels, int k, int* wk, int* hk) {
+    if (w <= 0 || h <= 0 || !(pyr_scale > 0 && pyr_scale < 1) || levels < 0 || k < 0) return RC_EINVAL;
+    RcLevel L;
+    level_geom(w, h, pyr_scale, k, L);
+    if (wk) *wk = L.w;
+    if (hk) *hk = L.h;
+    return crop_levels(w, h, pyr_scale, levels);
+}
+
+// smooth.cpp getGaussianKernel(n, sigma, CV_32F)
+static void host_gaussian_kernel(int n, double sigma, float* cf) {
+    static const float tab1[] = {1.f};
+    static const float tab3[] = {0.25f, 0.5f, 0.25f};
+    static const float tab5[] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    static const float tab7[] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f};
+    const float* fixed = nullptr;
+    if (n % 2 == 1 && n <= 7 && sigma <= 0) fixed = n == 1 ? tab1 : n == 3 ? tab3 : n == 5 ? tab5 : tab7;
+    double sx = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    double scale2x = -0.5 / (sx * sx), sum = 0;
+    for (int i = 0; i < n; i++) {
+        double x = i - (n - 1) * 0.5;
+        double t = fixed ? (double)fixed[i] : exp(scale2x * x * x);
+        cf[i] = (float)t;
+        sum += cf[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) cf[i] = (float)(cf[i] * sum);
+}
+
+// optflow.cpp FarnebackPrepareGaussian; the 6x6 moment matrix is inverted by Cholesky.
+static int host_prepare_poly(int n, double sigma, int exact_taps, RcPolyK& pk) {
+    if (sigma < FLT_EPSILON) sigma = n * 0.3;
+    std::vector<float> gb(2 * n + 1), xgb(2 * n + 1), xxgb(2 * n + 1);
+    float *g = gb.data() + n, *xg = xgb.data() + n, *xxg = xxgb.data() + n;
+    double s = 0.;
+    for (int x = -n; x <= n; x++) {
+        g[x] = (float)exp(-x * x / (2 * sigma * sigma));
+        s += g[x];
+    }
+    s = 1. / s;
+    for (int x = -n; x <= n; x++) {
+        g[x] = (float)(g[x] * s);
+        xg[x] = (float)(x * g[x]);
+        xxg[x] = (float)(x * x * g[x]);
+    }
+    double G[6][6] = {{0}};
+    for (int y = -n; y <= n; y++)
+        for (int x = -n; x <= n; x++) {
+            G[0][0] += g[y] * g[x];
+            G[1][1] += g[y] * g[x] * x * x;
+            G[3][3] += g[y] * g[x] * x * x * x * x;
+            G[5][5] += g[y] * g[x] * x * x * y * y;
+        }
+    G[2][2] = G[0][3] = G[0][4] = G[3][0] = G[4][0] = G[1][1];
+    G[4][4] = G[3][3];
+    G[3][4] = G[4][3] = G[5][5];
+    // Cholesky G = L L^T, then invG = L^-T L^-1
+    double L[6][6] = {{0}}, Li[6][6] = {{0}}, inv[6][6] = {{0}};
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j <= i; j++) {
+            double v = G[i][j];
+            for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k];
+            if (i == j) {
+                if (!(v > 0)) return RC_EINVAL;
+                L[i][i] = sqrt(v);
+            } else {
+                L[i][j] = v / L[j][j];
+            }
+        }
+    for (int c = 0; c < 6; c++)
+        for (int i = 0; i < 6; i++) {
+            double v = i == c ? 1. : 0.;
+            for (int k = 0; k < i; k++) v -= L[i][k] * Li[k][c];
+            Li[i][c] = v / L[i][i];
+        }
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++)
+            for (int k = 0; k < 6; k++) inv[i][j] += Li[k][i] * Li[k][j];
+    pk.ig11 = inv[1][1];
+    pk.ig03 = inv[0][3];
+    pk.ig33 = inv[3][3];
+    pk.ig55 = inv[5][5];
+    pk.n = n;
+    // Taps whose combined weight cannot change any sum beyond 1e-9 of its kernel mass are
+    // dropped (poly_n = 15 with sigma = 1.2 evaluates 19 of its 31 taps; "exact_taps"
+    // keeps all of them).
+    int n_thr = n;
+    if (!exact_taps) {
+        double m0 = 0, m1 = 0, m2 = 0;
+        for (int k = 1; k <= n; k++) { m0 += g[k]; m1 += fabs(xg[k]); m2 += xxg[k]; }
+        double t0 = 0, t1 = 0, t2 = 0;
+        for (int k = n; k >= 1; k--) {
+            t0 += g[k]; t1 += fabs(xg[k]); t2 += xxg[k];
+            if (t0 > 1e-9 * (m0 + g[0]) || t1 > 1e-9 * m1 || t2 > 1e-9 * m2) break;
+            n_thr = k - 1;
+        }
+        if (n_thr < 1) n_thr = 1;
+    }
+    static const int inst[] = {3, 5, 7, 9, 12, 16, 24, 32};
+    int R = 32;
+    for (int v : inst)
+        if (v >= n_thr) { R = v; break; }
+    pk.n_eff = R < n ? R : n;
+    memset(pk.g, 0, sizeof(pk.g));
+    memset(pk.xg, 0, sizeof(pk.xg));
+    memset(pk.xxg, 0, sizeof(pk.xxg));
+    double sg = 0, s2 = 0;
+    for (int k = 0; k <= pk.n_eff; k++) {
+        pk.g[k] = g[k];
+        pk.xg[k] = xg[k];
+        pk.xxg[k] = xxg[k];
+        sg += (k ? 2. : 1.) * g[k];
+        s2 += (k ? 2. : 0.) * xxg[k];
+    }
+    pk.kdc = sg * sg * pk.ig03 + sg * s2 * pk.ig33;
+    return RC_OK;
+}
+
+static void host_window(int winsize, int flags, RcWindow& win) {
+    int m = winsize / 2;
+    memset(&win, 0, sizeof(win));
+    win.m = m;
+    win.gaussian = (flags & RC_FARNEBACK_GAUSSIAN) ? 1 : 0;
+    win.box_scale = 1. / ((double)winsize * winsize);
+    double sigma = m * 0.3, s = 1;
+    win.k[0] = (float)s;
+    for (int i = 1; i <= m; i++) {
+        float t = (float)exp(-i * i / (2 * sigma * sigma));
+        win.k[i] = t;
+        s += t * 2;
+    }
+    s = 1. / s;
+    for (int i = 0; i <= m; i++) win.k[i] = (float)(win.k[i] * s);
+}
+
+static void pick_pyr_tile(RcLevel& L, int W0, int H0) {
+    static const int tiles[][2] = {{64, 4}, {32, 8}, {16, 8}, {16, 4}, {8, 4}, {4, 4}, {2, 2}, {1, 1}};
+    int r = L.ksize / 2;
+    for (auto& t : tiles) {
+        int tw = t[0], th = t[1];
+        int rw = (int)ceil(tw * L.scale_x) + 2 * r + 4;
+        int rh = (int)ceil(th * L.scale_y) + 2 * r + 4;
+        if (rw > W0 + 2 * r + 2) rw = W0 + 2 * r + 2;
+        if (rh > H0 + 2 * r + 2) rh = H0 + 2 * r + 2;
+        int rwp = (rw + 15) & ~15;
+        size_t lds = (size_t)rh * rwp + sizeof(float) * (size_t)rh * 2 * tw;
+        if (lds <= 60 * 1024 || tw == 1) {
+            L.pyr_tw = tw; L.pyr_th = th; L.pyr_reg_w = rwp; L.pyr_reg_h = rh; L.pyr_lds = lds;
+            return;
+        }
+    }
+}
+
+static void pick_iter_tile(RcPlan& pl) {
+    static const int tiles[][2] = {{64, 16}, {32, 32}, {64, 8}, {32, 16}, {16, 16}, {16, 8}, {8, 8}};
+    int m = pl.win.m;
+    double best = -1;
+    for (auto& t : tiles) {
+        size_t lds = rc_flow_iter_lds(t[0], t[1], m);
+        if (lds > 150 * 1024) continue;
+        double eff = (double)(t[0] * t[1]) / ((t[0] + 2 * m) * (t[1] + 2 * m));
+        if (lds > 64 * 1024) eff *= 0.6;      // one block per CU only
+        if (t[0] < 64) eff *= 0.95;           // 16-B coalescing prefers 64-wide rows
+        if (eff > best) { best = eff; pl.iter_tw = t[0]; pl.iter_th = t[1]; }
+    }
+}
+
+static int params_valid(const rc_farneback_params* p) {
+    if (!p) return 0;
+    if (!(p->pyr_scale > 0 && p->pyr_scale < 1)) return 0;
+    if (p->levels < 0 || p->levels >= RC_MAX_LEVELS) return 0;
+    if (p->winsize < 1 || p->winsize / 2 > 24) return 0;
+    if (p->iterations < 0 || p->iterations > 1000) return 0;
+    if (p->poly_n < 1 || p->poly_n > RC_MAX_POLY_N) return 0;
+    if (!(p->poly_sigma >= 0)) return 0;
+    if (p->flags & ~RC_FARNEBACK_GAUSSIAN) return 0;   // USE_INITIAL_FLOW unsupported
+    return 1;
+}
+
+static int ensure_plan(rc_ctx* ctx, RcSlot& s, int w, int h, const rc_farneback_params* p, int chunk) {
+    if (w <= 0 || h <= 0 || !params_valid(p)) {
+        rc_set_error("invalid Farneback arguments (w=%d h=%d)", w, h);
+        return RC_EINVAL;
+    }
+    if (w > ctx->max_w || h > ctx->max_h) {
+        rc_set_error("frame %dx%d exceeds the context's %dx%d", w, h, ctx->max_w, ctx->max_h);
+        return RC_ESIZE;
+    }
+    RcPlan& pl = s.plan;
+    if (pl.valid && pl.w == w && pl.h == h && !memcmp(&pl.prm, p, sizeof(*p)) && pl.chunk == chunk &&
+        pl.exact_taps == ctx->exact_taps)
+        return RC_OK;
+    RC_HIP(hipStreamSynchronize(s.cur));
+    pl.valid = false;
+    pl.w = w; pl.h = h; pl.prm = *p; pl.chunk = chunk; pl.nslots = chunk + 1;
+    pl.exact_taps = ctx->exact_taps;
+    int L = crop_levels(w, h, p->pyr_scale, p->levels);
+    pl.nlev = L + 1;
+    size_t kern_total = 0;
+    for (int k = 0; k <= L; k++) {
+        level_geom(w, h, p->pyr_scale, k, pl.lv[k]);
+        if (pl.lv[k].ksize > 1023) { rc_set_error("pyramid blur too wide"); return RC_EINVAL; }
+        pick_pyr_tile(pl.lv[k], w, h);
+        pl.kern_off[k] = kern_total;
+        kern_total += (pl.lv[k].ksize + 3) & ~3;
+    }
+    int rc = host_prepare_poly(p->poly_n, p->poly_sigma, ctx->exact_taps, pl.pk);
+    if (rc) { rc_set_error("polynomial-expansion moment matrix is not positive definite"); return rc; }
+    host_window(p->winsize, p->flags, pl.win);
+    pick_iter_tile(pl);
+
+    std::vector<float> kh(kern_total, 0.f);
+    for (int k = 0; k <= L; k++) host_gaussian_kernel(pl.lv[k].ksize, pl.lv[k].sigma > 0 ? pl.lv[k].sigma : 0., kh.data() + pl.kern_off[k]);
+    if ((rc = rc_buf_ensure(s.kern, kern_total * sizeof(float)))) return rc;
+    RC_HIP(hipMemcpy(s.kern.p, kh.data(), kern_total * sizeof(float), hipMemcpyHostToDevice));
+    for (int k = 0; k <= L; k++) {
+        size_t n = (size_t)pl.lv[k].w * pl.lv[k].h;
+        if ((rc = rc_buf_ensure(s.I[k], n * pl.nslots * sizeof(float)))) return rc;
+        if ((rc = rc_buf_ensure(s.RA[k], n * pl.nslots * sizeof(float4)))) return rc;
+        if ((rc = rc_buf_ensure(s.RB[k], n * pl.nslots * sizeof(float)))) return rc;
+        if ((rc = rc_buf_ensure(s.FA[k], n * chunk * sizeof(float2)))) return rc;
+        if ((rc = rc_buf_ensure(s.FB[k], n * chunk * sizeof(float2)))) return rc;
+    }
+    s.primed = 0;
+    pl.valid = true;
+    return RC_OK;
+}
+
+// ---------------------------------------------------------------------------- level driver
+// Pyramid + polynomial expansion of `count` frames into R slots dslot0.. (A1 + A2).
+static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t frame_stride, size_t step,
+                         int count, int dslot0) {
+    RcPlan& pl = s.plan;
+    for (int k = 0; k < pl.nlev; k++) {
+        const RcLevel& L = pl.lv[k];
+        size_t n = (size_t)L.w * L.h;
+        RcPyrArgs pa;
+        pa.src = d_src; pa.src_step = step; pa.src_frame_stride = frame_stride;
+        pa.W0 = pl.w; pa.H0 = pl.h;
+        pa.dst = (float*)s.I[k].p; pa.dst_slot_stride = n;
+        pa.dslot0 = dslot0; pa.nslots = pl.nslots;
+        pa.w = L.w; pa.h = L.h; pa.scale_x = L.scale_x; pa.scale_y = L.scale_y;
+        pa.ksize = L.ksize; pa.kern = (const float*)s.kern.p + pl.kern_off[k];
+        pa.tw = L.pyr_tw; pa.th = L.pyr_th; pa.reg_wp = L.pyr_reg_w; pa.reg_hmax = L.pyr_reg_h;
+        {
+            RcProfScope ps(ctx, s.cur, RC_K_PYR, k, (double)count * ((double)pl.w * pl.h + 4. * n));
+            rc_launch_pyr(pa, count, L.pyr_lds, s.cur);
+        }
+        RcPolyArgs qa;
+        qa.I = (const float*)s.I[k].p; qa.I_slot_stride = n;
+        qa.RA = (float4*)s.RA[k].p; qa.RB = (float*)s.RB[k].p; qa.R_slot_stride = n;
+        qa.slot0 = dslot0; qa.nslots = pl.nslots; qa.w = L.w; qa.h = L.h; qa.pk = pl.pk;
+        {
+            RcProfScope ps(ctx, s.cur, RC_K_POLY, k, (double)count * 24. * n);
+            rc_launch_polyexp(qa, count, s.cur);
+        }
+    }
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+// Coarse-to-fine flow for `pairs` frame pairs whose expansions sit in slots slot0+z, slot0+z+1.
+static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_out, size_t out_pair_stride,
+                         size_t out_step) {
+    RcPlan& pl = s.plan;
+    const int iters = pl.prm.iterations;
+    const float2* coarse = nullptr;
+    int cw = 0, ch = 0;
+    for (int k = pl.nlev - 1; k >= 0; k--) {
+        const RcLevel& L = pl.lv[k];
+        size_t n = (size_t)L.w * L.h;
+        RcIterArgs a;
+        memset(&a, 0, sizeof(a));
+        a.RA = (const float4*)s.RA[k].p; a.RB = (const float*)s.RB[k].p; a.R_slot_stride = n;
+        a.slot0 = slot0; a.slot1 = (slot0 + 1) % pl.nslots; a.nslots = pl.nslots;
+        a.w = L.w; a.h = L.h;
+        a.tw = pl.iter_tw; a.th = pl.iter_th;
+        a.tiles_x = (L.w + a.tw - 1) / a.tw; a.tiles_y = (L.h + a.th - 1) / a.th;
+        a.win = pl.win;
+        const float2* cur_in = nullptr;
+        int passes = iters > 0 ? iters : 1;
+        for (int i = 0; i < passes; i++) {
+            double in_bytes;
+            if (i == 0) {
+                if (!coarse) { a.in_mode = 0; a.fin = nullptr; in_bytes = 0; }
+                else {
+                    a.in_mode = 2; a.fin = coarse; a.fin_pair_stride = (size_t)cw * ch;
+                    a.fin_w = cw; a.fin_h = ch;
+                    a.up_scale_x = 1. / ((double)L.w / cw);
+                    a.up_scale_y = 1. / ((double)L.h / ch);
+                    a.up_mul = (float)(1. / pl.prm.pyr_scale);
+                    in_bytes = 8. * cw * ch;
+                }
+            } else {
+                a.in_mode = 1; a.fin = cur_in; a.fin_pair_stride = n; in_bytes = 8. * n;
+            }
+            bool last = (i == passes - 1);
+            if (last && k == 0) {
+                a.fout = (char*)d_out; a.fout_step = out_step; a.fout_pair_stride = out_pair_stride;
+            } else {
+                float2* dst = (float2*)((i & 1) ? s.FB[k].p : s.FA[k].p);
+                a.fout = (char*)dst; a.fout_step = (size_t)L.w * 8; a.fout_pair_stride = n * 8;
+                cur_in = dst;
+            }
+            a.solve = iters > 0 ? 1 : 0;
+            {
+                RcProfScope ps(ctx, s.cur, RC_K_ITER, k, (double)pairs * ((a.solve ? 40. : 0.) * n + in_bytes + 8. * n));
+                rc_launch_flow_iter(a, pairs, s.cur);
+            }
+        }
+        coarse = cur_in;
+        cw = L.w; ch = L.h;
+    }
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+// ---------------------------------------------------------------------------- A entry points
+extern "C" int rcflow_farneback_dev(rc_ctx* ctx, int stream, const uint8_t* d_prev, size_t prev_step,
+                                    const uint8_t* d_next, size_t next_step, int w, int h, float* d_flow,
+                                    size_t flow_step, const rc_farneback_params* p) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !d_prev || !d_next || !d_flow) { if (s) rc_set_error("null image pointer"); return RC_EINVAL; }
+    if (prev_step < (size_t)w || next_step < (size_t)w || flow_step < (size_t)w * 8) {
+        rc_set_error("row step smaller than a row");
+        return RC_EINVAL;
+    }
+    RC_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_plan(ctx, *s, w, h, p, ctx->chunk);
+    if (rc) return rc;
+    s->primed = 0;
+    if ((rc = expand_frames(ctx, *s, d_prev, 0, prev_step, 1, 0))) return rc;
+    if ((rc = expand_frames(ctx, *s, d_next, 0, next_step, 1, 1))) return rc;
+    return compute_flows(ctx, *s, 1, 0, d_flow, 0, flow_step);
+}
+
+extern "C" int rcflow_farneback_u8(rc_ctx* ctx, int stream, const uint8_t* prev, size_t prev_step,
+                                   const uint8_t* next, size_t next_step, int w, int h, float* flow,
+                                   size_t flow_step, double pyr_scale, int levels, int winsize, int iterations,
+                                   int poly_n, double poly_sigma, int flags) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !prev || !next || !flow || w <= 0 || h <= 0) { if (s) rc_set_error("null image pointer"); return RC_EINVAL; }
+    if (prev_step < (size_t)w || next_step < (size_t)w || flow_step < (size_t)w * 8) {
+        rc_set_error("row step smaller than a row");
+        return RC_EINVAL;
+    }
+    rc_farneback_params p = {pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags};
+    RC_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_plan(ctx, *s, w, h, &p, ctx->chunk);
+    if (rc) return rc;
+    size_t fb = (size_t)w * h;
+    if ((rc = rc_buf_ensure(s->stage_u8, 2 * fb))) return rc;
+    if ((rc = rc_buf_ensure(s->stage_flow, fb * 8))) return rc;
+    uint8_t* du = (uint8_t*)s->stage_u8.p;
+    RC_HIP(hipMemcpy2DAsync(du, w, prev, prev_step, w, h, hipMemcpyHostToDevice, s->cur));
+    RC_HIP(hipMemcpy2DAsync(du + fb, w, next, next_step, w, h, hipMemcpyHostToDevice, s->cur));
+    rc = rcflow_farneback_dev(ctx, stream, du, w, du + fb, w, w, h, (float*)s->stage_flow.p, (size_t)w * 8, &p);
+    if (rc) return rc;
+    RC_HIP(hipMemcpy2DAsync(flow, flow_step, s->stage_flow.p, (size_t)w * 8, (size_t)w * 8, h,
+                            hipMemcpyDeviceToHost, s->cur));
+    RC_HIP(hipStreamSynchronize(s->cur));
+    return RC_OK;
+}
+
+extern "C" int rcflow_stream_reset(rc_ctx* ctx, int stream) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    s->primed = 0;
+    s->cur_slot = 0;
+    return RC_OK;
+}
+
+extern "C" int rcflow_push_frame_dev(rc_ctx* ctx, int stream, const uint8_t* d_frame, size_t step, int w, int h,
+                                     float* d_flow, size_t flow_step, const rc_farneback_params* p) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !d_frame) { if (s) rc_set_error("null frame pointer"); return RC_EINVAL; }
+    if (step < (size_t)w) { rc_set_error("row step smaller than a row"); return RC_EINVAL; }
+    RC_HIP(hipSetDevice(ctx->device));
+    int was_valid = s->plan.valid;
+    int rc = ensure_plan(ctx, *s, w, h, p, ctx->chunk);
+    if (rc) return rc;
+    if (!was_valid) s->primed = 0;
+    if (!s->primed) {
+        if ((rc = expand_frames(ctx, *s, d_frame, 0, step, 1, 0))) return rc;
+        s->primed = 1;
+        s->cur_slot = 0;
+        return 1;
+    }
+    if (!d_flow || flow_step < (size_t)w * 8) { rc_set_error("bad flow buffer"); return RC_EINVAL; }
+    int nxt = (s->cur_slot + 1) % s->plan.nslots;
+    if ((rc = expand_frames(ctx, *s, d_frame, 0, step, 1, nxt))) return rc;
+    if ((rc = compute_flows(ctx, *s, 1, s->cur_slot, d_flow, 0, flow_step))) return rc;
+    s->cur_slot = nxt;
+    return RC_OK;
+}
+
+extern "C" int rcflow_farneback_clip_dev(rc_ctx* ctx, int stream, const uint8_t* d_frames, size_t frame_stride,
+                                         size_t step, int nframes, int w, int h, float* d_flows,
+                                         size_t flow_frame_stride, size_t flow_step,
+                                         const rc_farneback_params* p) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !d_frames || !d_flows || nframes < 2) { if (s) rc_set_error("bad clip arguments"); return RC_EINVAL; }
+    if (step < (size_t)w || flow_step < (size_t)w * 8 || frame_stride < step * (size_t)(h - 1) + w ||
+        flow_frame_stride < flow_step * (size_t)(h - 1) + (size_t)w * 8) {
+        rc_set_error("clip strides smaller than a frame");
+        return RC_EINVAL;
+    }
+    RC_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_plan(ctx, *s, w, h, p, ctx->chunk);
+    if (rc) return rc;
+    s->primed = 0;
+    const int C = s->plan.chunk, ns = s->plan.nslots;
+    int s0 = 0;
+    if ((rc = expand_frames(ctx, *s, d_frames, frame_stride, step, 1, 0))) return rc;
+    for (int t = 0; t < nframes - 1;) {
+        int np = nframes - 1 - t < C ? nframes - 1 - t : C;
+        if ((rc = expand_frames(ctx, *s, d_frames + (size_t)(t + 1) * frame_stride, frame_stride, step, np,
+                                (s0 + 1) % ns)))
+            return rc;
+        if ((rc = compute_flows(ctx, *s, np, s0, (float*)((char*)d_flows + (size_t)t * flow_frame_stride),
+                                flow_frame_stride, flow_step)))
+            return rc;
+        s0 = (s0 + np) % ns;
+        t += np;
+    }
+    return RC_OK;
+}
+
+// ---------------------------------------------------------------------------- stage entry points
+extern "C" int rcflow_stage_pyr_level_dev(rc_ctx* ctx, int stream, const uint8_t* d_img, size_t step, int w,
+                                          int h, double pyr_scale, int k, float* d_out) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !d_img || !d_out || k < 0 || k >= RC_MAX_LEVELS || !(pyr_scale > 0 && pyr_scale < 1)) return RC_EINVAL;
+    RC_HIP(hipSetDevice(ctx->device));
+    RcLevel L;
+    level_geom(w, h, pyr_scale, k, L);
+    pick_pyr_tile(L, w, h);
+    std::vector<float> kh(L.ksize);
+    host_gaussian_kernel(L.ksize, L.sigma > 0 ? L.sigma : 0., kh.data());
+    int rc = rc_buf_ensure(s->stage_f32[0], kh.size() * sizeof(float));
+    if (rc) return rc;
+    RC_HIP(hipMemcpyAsync(s->stage_f32[0].p, kh.data(), kh.size() * sizeof(float), hipMemcpyHostToDevice, s->cur));
+    RC_HIP(hipStreamSynchronize(s->cur));
+    RcPyrArgs pa;
+    pa.src = d_img; pa.src_step = step; pa.src_frame_stride = 0; pa.W0 = w; pa.H0 = h;
+    pa.dst = d_out; pa.dst_slot_stride = 0; pa.dslot0 = 0; pa.nslots = 1;
+    pa.w = L.w; pa.h = L.h; pa.scale_x = L.scale_x; pa.scale_y = L.scale_y;
+    pa.ksize = L.ksize; pa.kern = (const float*)s->stage_f32[0].p;
+    pa.tw = L.pyr_tw; pa.th = L.pyr_th; pa.reg_wp = L.pyr_reg_w; pa.reg_hmax = L.pyr_reg_h;
+    rc_launch_pyr(pa, 1, L.pyr_lds, s->cur);
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+extern "C" int rcflow_stage_polyexp_dev(rc_ctx* ctx, int stream, const float* d_I, int w, int h, int poly_n,
+                                        double poly_sigma, float* d_R5) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !d_I || !d_R5 || w <= 0 || h <= 0 || poly_n < 1 || poly_n > RC_MAX_POLY_N) return RC_EINVAL;
+    RC_HIP(hipSetDevice(ctx->device));
+    size_t n = (size_t)w * h;
+    int rc;
+    if ((rc = rc_buf_ensure(s->stage_f32[0], n * sizeof(float4)))) return rc;
+    if ((rc = rc_buf_ensure(s->stage_f32[1], n * sizeof(float)))) return rc;
+    RcPolyArgs qa;
+    qa.I = d_I; qa.I_slot_stride = 0;
+    qa.RA = (float4*)s->stage_f32[0].p; qa.RB = (float*)s->stage_f32[1].p; qa.R_slot_stride = 0;
+    qa.slot0 = 0; qa.nslots = 1; qa.w = w; qa.h = h;
+    if ((rc = host_prepare_poly(poly_n, poly_sigma, ctx->exact_taps, qa.pk))) return rc;
+    rc_launch_polyexp(qa, 1, s->cur);
+    rc_launch_unpack_R5(qa.RA, qa.RB, d_R5, (int)n, s->cur);
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+extern "C" int rcflow_stage_flow_iter_dev(rc_ctx* ctx, int stream, const float* d_R0, const float* d_R1,
+                                          const float* d_flow_in, int w, int h, int winsize, int flags,
+                                          float* d_flow_out) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !d_R0 || !d_R1 || !d_flow_out || w <= 0 || h <= 0 || winsize < 1 || winsize / 2 > 24 ||
+        (flags & ~RC_FARNEBACK_GAUSSIAN))
+        return RC_EINVAL;
+    RC_HIP(hipSetDevice(ctx->device));
+    size_t n = (size_t)w * h;
+    int rc;
+    if ((rc = rc_buf_ensure(s->stage_f32[0], 2 * n * sizeof(float4)))) return rc;
+    if ((rc = rc_buf_ensure(s->stage_f32[1], 2 * n * sizeof(float)))) return rc;
+    float4* RA = (float4*)s->stage_f32[0].p;
+    float* RB = (float*)s->stage_f32[1].p;
+    rc_launch_pack_R5(d_R0, RA, RB, (int)n, s->cur);
+    rc_launch_pack_R5(d_R1, RA + n, RB + n, (int)n, s->cur);
+    RcPlan tmp;
+    host_window(winsize, flags, tmp.win);
+    pick_iter_tile(tmp);
+    RcIterArgs a;
+    memset(&a, 0, sizeof(a));
+    a.RA = RA; a.RB = RB; a.R_slot_stride = n; a.slot0 = 0; a.slot1 = 1; a.nslots = 2;
+    a.w = w; a.h = h;
+    a.in_mode = d_flow_in ? 1 : 0; a.fin = (const float2*)d_flow_in; a.fin_pair_stride = n;
+    a.fout = (char*)d_flow_out; a.fout_step = (size_t)w * 8; a.fout_pair_stride = n * 8;
+    a.tw = tmp.iter_tw; a.th = tmp.iter_th;
+    a.tiles_x = (w + a.tw - 1) / a.tw; a.tiles_y = (h + a.th - 1) / a.th;
+    a.solve = 1; a.win = tmp.win;
+    rc_launch_flow_iter(a, 1, s->cur);
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}

@@ -1,0 +1,264 @@
+"""GPU parity tests for the Farneback path (A1-A7): librcflow (HIP, through the C ABI) vs the
+CPU oracle on the same seeded inputs.
+
+Tolerances (float path):
+  * pyramid level (A1):           bit-exact (same operation order, no contraction)
+  * polynomial expansion (A2):    |dR| <= 2e-4 absolute on coefficients of O(1..100)
+                                  (oracle: float vertical + double horizontal sums; HIP: fp32
+                                  sums on DC-removed data + double epilogue)
+  * one flow iteration (A3-A6):   |dflow| <= 1e-3 px on >= 99.9 % of pixels, given identical R
+  * end to end:                   |dflow| <= 1e-3 px on >= 99 % (box window) of pixels; the
+                                  coarse-to-fine recursion amplifies rounding differences at
+                                  pixels whose 2x2 system is near-singular, so the tail is
+                                  bounded by a percentile, not by a maximum.
+"""
+import numpy as np
+import pytest
+import torch
+
+from ripcurrents_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+RC215 = dict(pyr_scale=0.5, levels=2, winsize=3, iterations=2, poly_n=15, poly_sigma=1.2, flags=0)
+MAIN264 = dict(RC215, flags=256)
+MAIN609 = dict(RC215, winsize=20, iterations=3, flags=256)
+MAIN1119 = dict(RC215, winsize=10, iterations=3, flags=256)
+AND167 = dict(RC215, levels=3, winsize=5, iterations=3)
+
+
+def _oracle_flow(orc, a, b, p):
+    return orc.farneback(a, b, p["pyr_scale"], p["levels"], p["winsize"], p["iterations"], p["poly_n"],
+                         p["poly_sigma"], p["flags"])
+
+
+def _report(name, got, ref):
+    err = np.abs(got - ref).max(-1)
+    stats = dict(max=float(err.max()), p50=float(np.percentile(err, 50)), p99=float(np.percentile(err, 99)),
+                 p999=float(np.percentile(err, 99.9)), frac_1e3=float((err <= 1e-3).mean()))
+    print("\n[parity] %s: %s" % (name, stats))
+    return stats
+
+
+@pytest.mark.parametrize("size,k", [((640, 480), 0), ((640, 480), 1), ((640, 480), 2), ((333, 251), 1),
+                                    ((1920, 1080), 2), ((97, 65), 0)])
+def test_pyr_level_bit_exact(ctx, orc, size, k):
+    w, h = size
+    img = synth.surf_clip(w, h, 1, seed=7)[0]
+    g = orc.level_geometry(w, h, 0.5, 8, k)
+    ref = orc.pyr_level(img, g["sigma"], g["ksize"], g["w"], g["h"])
+    got = ctx.stage_pyr_level(img, 0.5, k).cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref), "max diff %g" % np.abs(got - ref).max()
+
+
+def test_pyr_level_noninteger_scale(ctx, orc):
+    w, h = 500, 375
+    img = synth.surf_clip(w, h, 1, seed=3)[0]
+    for k in (1, 2, 3):
+        g = orc.level_geometry(w, h, 0.8, 8, k)
+        ref = orc.pyr_level(img, g["sigma"], g["ksize"], g["w"], g["h"])
+        got = ctx.stage_pyr_level(img, 0.8, k).cpu().numpy()
+        assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("size", [(640, 480), (130, 70), (64, 32), (1920, 1080)])
+@pytest.mark.parametrize("n,sigma", [(15, 1.2), (5, 1.1), (7, 1.5)])
+def test_polyexp(ctx, orc, size, n, sigma):
+    w, h = size
+    if (w, h) == (1920, 1080) and n != 15:
+        pytest.skip("full size only for the reference's parameters")
+    img = synth.surf_clip(w, h, 1, seed=11)[0]
+    I = orc.pyr_level(img, 0.0, 3, w, h)
+    ref = orc.polyexp(I, n, sigma)
+    got = ctx.stage_polyexp(I, n, sigma).cpu().numpy()
+    err = np.abs(got - ref)
+    print("\n[parity] polyexp %dx%d n=%d: max %g, rel-to-max %g" % (w, h, n, err.max(), err.max() / np.abs(ref).max()))
+    assert err.max() <= 2e-4
+
+
+def test_polyexp_exact_taps_option(ctx, orc):
+    """Dropping the negligible taps (default) vs evaluating all 31 moves R by < 1e-5."""
+    img = synth.surf_clip(320, 240, 1, seed=5)[0]
+    I = orc.pyr_level(img, 0.0, 3, 320, 240)
+    a = ctx.stage_polyexp(I, 15, 1.2).cpu().numpy()
+    ctx.set_option("exact_taps", 1)
+    try:
+        b = ctx.stage_polyexp(I, 15, 1.2).cpu().numpy()
+    finally:
+        ctx.set_option("exact_taps", 0)
+    ref = orc.polyexp(I, 15, 1.2)
+    assert np.abs(a - b).max() < 1e-5
+    assert np.abs(b - ref).max() <= 2e-4
+
+
+def test_polyexp_quadratic_known_answer(ctx):
+    """Analytic KAT: for I = a + b x + c y + d x^2 + e y^2 + f xy the interior output is
+    (c', b', e, d, f) with first-order terms evaluated at the pixel."""
+    h, w = 96, 128
+    ys, xs = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    a, b, c, d, e, f = 20.0, 0.5, -0.25, 0.01, -0.02, 0.015
+    I = (a + b * xs + c * ys + d * xs * xs + e * ys * ys + f * xs * ys).astype(np.float32)
+    R = ctx.stage_polyexp(I, 15, 1.2).cpu().numpy()
+    m = 20
+    Ri = R[m:-m, m:-m].astype(np.float64)
+    xi, yi = xs[m:-m, m:-m], ys[m:-m, m:-m]
+    assert np.abs(Ri[..., 0] - (c + 2 * e * yi + f * xi)).max() < 2e-3
+    assert np.abs(Ri[..., 1] - (b + 2 * d * xi + f * yi)).max() < 2e-3
+    assert np.abs(Ri[..., 2] - e).max() < 2e-3
+    assert np.abs(Ri[..., 3] - d).max() < 2e-3
+    assert np.abs(Ri[..., 4] - f).max() < 2e-3
+
+
+@pytest.mark.parametrize("winsize,flags", [(3, 0), (3, 256), (10, 256), (20, 256), (5, 0), (4, 0)])
+def test_flow_iteration_stage(ctx, orc, winsize, flags):
+    """One UpdateMatrices + window + solve on identical R0, R1, flow_in."""
+    w, h = 320, 240
+    clip = synth.surf_clip(w, h, 2, seed=21)
+    I0 = orc.pyr_level(clip[0], 0.0, 3, w, h)
+    I1 = orc.pyr_level(clip[1], 0.0, 3, w, h)
+    R0, R1 = orc.polyexp(I0), orc.polyexp(I1)
+    rng = np.random.RandomState(1)
+    fin = (rng.randn(h, w, 2) * 1.5).astype(np.float32)
+    M = orc.update_matrices(R0, R1, fin)
+    ref = fin.copy()
+    orc.update_flow(R0, R1, ref, M, winsize, False, bool(flags & 256))
+    got = ctx.stage_flow_iter(R0, R1, fin, winsize, flags).cpu().numpy()
+    st = _report("flow_iter win=%d flags=%d" % (winsize, flags), got, ref)
+    assert st["frac_1e3"] >= 0.999
+    # zero initial flow = the coarsest-level case
+    M = orc.update_matrices(R0, R1, np.zeros_like(fin))
+    ref0 = np.zeros_like(fin)
+    orc.update_flow(R0, R1, ref0, M, winsize, False, bool(flags & 256))
+    got0 = ctx.stage_flow_iter(R0, R1, None, winsize, flags).cpu().numpy()
+    assert (np.abs(got0 - ref0).max(-1) <= 1e-3).mean() >= 0.999
+
+
+@pytest.mark.parametrize("name,p,size,minfrac", [
+    ("RC215 640x480", RC215, (640, 480), 0.99),
+    ("MAIN264 gaussian win3", MAIN264, (640, 480), 0.85),
+    ("MAIN609 win20", MAIN609, (640, 480), 0.99),
+    ("MAIN1119 win10", MAIN1119, (640, 480), 0.99),
+    ("AND167 levels3 win5", AND167, (640, 480), 0.99),
+    ("ragged 333x251", RC215, (333, 251), 0.99),
+    ("tiny 40x36 (levels cropped)", RC215, (40, 36), 0.97),
+])
+def test_end_to_end_parity(ctx, orc, name, p, size, minfrac):
+    w, h = size
+    clip = synth.surf_clip(w, h, 2, seed=1234)
+    ref = _oracle_flow(orc, clip[0], clip[1], p)
+    got = ctx.calcOpticalFlowFarneback(clip[0], clip[1], None, **p)
+    st = _report(name, got, ref)
+    assert st["frac_1e3"] >= minfrac
+    assert st["p50"] <= 1e-4
+
+
+def test_device_entry_point_matches_host_entry_point(ctx):
+    clip = synth.surf_clip(320, 240, 2, seed=9)
+    a = ctx.calcOpticalFlowFarneback(clip[0], clip[1], None, **RC215)
+    d = torch.as_tensor(clip).cuda()
+    b = ctx.calcOpticalFlowFarneback(d[0], d[1], None, **RC215)
+    ctx.sync()
+    assert np.array_equal(a, b.cpu().numpy())
+
+
+def test_strided_buffers(ctx):
+    """cv::Mat-style row steps on inputs and output."""
+    clip = synth.surf_clip(300, 200, 2, seed=2)
+    big = np.zeros((2, 200, 352), np.uint8)
+    big[:, :, :300] = clip
+    flow_big = np.full((200, 320, 2), np.nan, np.float32)
+    a = ctx.calcOpticalFlowFarneback(clip[0], clip[1], None, **RC215)
+    ctx.calcOpticalFlowFarneback(big[0, :, :300], big[1, :, :300], flow_big[:, :300], **RC215)
+    assert np.array_equal(flow_big[:, :300], a)
+    assert np.isnan(flow_big[:, 300:]).all()
+
+
+def test_zero_motion_and_translation(ctx):
+    """Analytic KATs: identical frames give exactly zero flow away from
+    the last rows/columns; a translated texture recovers the translation."""
+    clip = synth.translating_clip(640, 480, 2, u=1.25, v=-0.75)
+    z = ctx.calcOpticalFlowFarneback(clip[0], clip[0], None, **RC215)
+    assert np.abs(z[:-24, :-24]).max() == 0.0
+    f = ctx.calcOpticalFlowFarneback(clip[0], clip[1], None, **RC215)
+    inner = f[40:-40, 40:-40]
+    assert abs(np.median(inner[..., 0]) - 1.25) < 0.08
+    assert abs(np.median(inner[..., 1]) + 0.75) < 0.08
+
+
+def test_clip_and_streaming_match_pairwise(ctx):
+    """Clip batching (chunks of pairs per launch) and the streaming push_frame path give
+    bit-identical flows to the two-image call."""
+    T, w, h = 7, 320, 240
+    clip = synth.surf_clip(w, h, T, seed=77)
+    d = torch.as_tensor(clip).cuda()
+    flows = ctx.farneback_clip(d, **RC215)
+    ctx.sync()
+    flows = flows.cpu().numpy()
+    for t in range(T - 1):
+        ref = ctx.calcOpticalFlowFarneback(clip[t], clip[t + 1], None, **RC215)
+        assert np.array_equal(flows[t], ref), "pair %d" % t
+    ctx.stream_reset()
+    outs = []
+    for t in range(T):
+        r = ctx.push_frame(d[t], **RC215)
+        if r is not None:
+            ctx.sync()
+            outs.append(r.cpu().numpy())
+    assert len(outs) == T - 1
+    for t in range(T - 1):
+        assert np.array_equal(outs[t], flows[t])
+
+
+def test_chunk_option_invariance(ctx):
+    clip = torch.as_tensor(synth.surf_clip(256, 192, 6, seed=4)).cuda()
+    a = ctx.farneback_clip(clip, **RC215).cpu().numpy()
+    for c in (1, 2, 5):
+        ctx.set_option("chunk", c)
+        b = ctx.farneback_clip(clip, **RC215).cpu().numpy()
+        assert np.array_equal(a, b)
+    ctx.set_option("chunk", 4)
+
+
+def test_full_size_1080p_parity(ctx, orc):
+    """BASELINE config 2 at full size against the oracle (one pair, ~2 s of CPU)."""
+    clip = synth.surf_clip(1920, 1080, 2, seed=1234)
+    ref = _oracle_flow(orc, clip[0], clip[1], RC215)
+    got = ctx.calcOpticalFlowFarneback(clip[0], clip[1], None, **RC215)
+    st = _report("C2 1080p RC215", got, ref)
+    assert st["frac_1e3"] >= 0.99 and st["p50"] <= 1e-4
+
+
+def test_4k_five_scales_properties(ctx):
+    """BASELINE config 3 (3840x2160, levels=4): size-independent properties instead of the
+    oracle: zero motion -> zero interior flow; flipping both frames left-right mirrors the flow."""
+    p = dict(RC215, levels=4)
+    clip = synth.surf_clip(3840, 2160, 2, seed=5)
+    d = torch.as_tensor(clip).cuda()
+    z = ctx.calcOpticalFlowFarneback(d[0], d[0], None, **p)
+    ctx.sync()
+    assert float(z[:-80, :-80].abs().max()) == 0.0
+    f = ctx.calcOpticalFlowFarneback(d[0], d[1], None, **p).clone()
+    fm = ctx.calcOpticalFlowFarneback(d[0].flip(1).contiguous(), d[1].flip(1).contiguous(), None, **p)
+    ctx.sync()
+    fm = fm.flip(1)
+    core = (slice(100, -100), slice(100, -100))
+    ex = (f[..., 0][core] + fm[..., 0][core]).abs()
+    ey = (f[..., 1][core] - fm[..., 1][core]).abs()
+    # mirror symmetry is broken only by the one-sided border rule (x1 < w-1) and rounding
+    assert float((ex < 1e-2).float().mean()) > 0.99 and float((ey < 1e-2).float().mean()) > 0.99
+
+
+def test_error_codes(ctx):
+    from ripcurrents_amd import RcflowError
+    a = np.zeros((64, 64), np.uint8)
+    with pytest.raises(RcflowError) as e:
+        ctx.calcOpticalFlowFarneback(a, a, None, 1.5, 2, 3, 2, 15, 1.2, 0)      # pyr_scale >= 1
+    assert e.value.code == -1
+    with pytest.raises(RcflowError) as e:
+        ctx.calcOpticalFlowFarneback(a, a, None, 0.5, 2, 3, 2, 15, 1.2, 4)      # USE_INITIAL_FLOW
+    assert e.value.code == -1
+    big = np.zeros((2200, 4000), np.uint8)
+    with pytest.raises(RcflowError) as e:
+        ctx.calcOpticalFlowFarneback(big, big, None, **RC215)
+    assert e.value.code == -5
