@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of dense Farneback flow @1080p on N MI355X GPUs (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE config 2; config 4 when N>1): a synthetic 1920x1080 surf clip resident in
+HBM, 3 pyramid scales (levels=2), the parameter set of ripcurrents.cpp:215
+(0.5, 2, 3, 2, 15, 1.2, flags 0).  One STEP = one pass of the hot path over one clip of
+`--pairs`+1 frames: every frame is expanded once (pyramid + polynomial expansion, streaming
+model) and `--pairs` flow fields are produced, then the segment's flow histogram is
+accumulated (and, for N>1, all-reduced over RCCL: 1887 int32).  Each rank owns an
+independent segment (seed 1234+rank): weak scaling, no data-path collective.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP events on the kernel's
+stream inside the timed region) and, at N=1, `cpu_baseline` (the CPU oracle timed on this
+host on a bounded sample of the same clip).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+W, H = 1920, 1080
+PARAMS = dict(pyr_scale=0.5, levels=2, winsize=3, iterations=2, poly_n=15, poly_sigma=1.2, flags=0)
+
+
+def survey_model_bytes_per_frame(w, h, levels, iters):
+    """SURVEY.md section 8(d) algorithmic bytes per frame (streaming model)."""
+    n0 = w * h
+    total = 0
+    nk_prev = None
+    sizes = [(round(w * 0.5 ** k), round(h * 0.5 ** k)) for k in range(levels + 1)]
+    for k in range(levels, -1, -1):
+        nk = sizes[k][0] * sizes[k][1]
+        b = n0 + 4 * nk + 24 * nk + 60 * nk + (iters - 1) * 80 * nk + 28 * nk
+        if nk_prev is not None:
+            b += 8 * nk_prev
+        total += b
+        nk_prev = nk
+    return total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=32, help="frame pairs (flow fields) per step")
+    ap.add_argument("--chunk", type=int, default=0, help="pairs per launch (0 = library default)")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=6)
+    ap.add_argument("--gaussian", action="store_true", help="main.cpp:264 variant (flags=256)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            print("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus, file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ripcurrents_amd import synth
+    from ripcurrents_amd.api import Context
+
+    params = dict(PARAMS)
+    if args.gaussian:
+        params["flags"] = 256
+    T = args.pairs + 1
+    frames = synth.surf_clip(W, H, T, seed=1234 + rank, device=dev)      # generated in HBM
+    flows = torch.empty((args.pairs, H, W, 2), dtype=torch.float32, device=dev)
+    ctx = Context(W, H, device=local_rank, streams=1)
+    if args.chunk:
+        ctx.set_option("chunk", args.chunk)
+    ctx.analysis_reset(W, H)
+    hist_words = ctx.histogram_words()
+
+    def step():
+        ctx.farneback_clip(frames, flows, **params)
+        ctx.histogram_accumulate_clip(flows)
+        if world > 1:
+            # global flow histogram: integer sum, order independent
+            g = hist_words.clone()
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        ctx.thresholds()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if not args.no_kernel_events:
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    prof = []
+    if not args.no_kernel_events:
+        ctx.profile_enable(False)
+        prof = ctx.profile_read()
+
+    if rank == 0:
+        frames_done = world * args.pairs * args.steps
+        fps = frames_done / elapsed
+        model_b = survey_model_bytes_per_frame(W, H, params["levels"], params["iterations"])
+        out = {
+            "metric": "frames/sec dense Farneback flow @1080p",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C2 1920x1080 synthetic surf clip, 3 pyramid scales (levels=2), "
+                                   "winsize 3, iters 2, poly_n 15, sigma 1.2, flags %d; %d flow fields per "
+                                   "step per GPU, streaming model (one expansion per frame); + flow histogram"
+                                   % (params["flags"], args.pairs),
+                       "pairs_per_step": args.pairs, "segments": world,
+                       "collective": "all_reduce int32[1887] per step" if world > 1 else "none"},
+            "survey_model": {"bytes_per_frame": model_b,
+                             "frac_of_8TBs": round(fps / world * model_b / (HBM_PEAK_GBS * 1e9), 4)},
+        }
+        if prof:
+            tot = sum(p["total_ms"] for p in prof)
+            dom = max(prof, key=lambda p: p["total_ms"])
+            ach = dom["alg_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(ach, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                               "traffic": None,
+                               "avg_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
+                               "alg_bytes_per_launch": dom["alg_bytes"] / dom["launches"],
+                               "share_of_gpu_time": round(dom["total_ms"] / tot, 3)}
+            out["kernels"] = [{"kernel": p["kernel"], "launches": p["launches"],
+                               "avg_us": round(1e3 * p["total_ms"] / p["launches"], 2),
+                               "GBs": round(p["alg_bytes"] / (p["total_ms"] * 1e-3) / 1e9, 1)} for p in prof]
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle   # checker timed as the CPU baseline, never the product
+            host = frames[:args.cpu_pairs + 1].cpu().numpy()
+            oracle.farneback(host[0][:270, :480], host[1][:270, :480])    # warm the library
+            tc = time.perf_counter()
+            for t in range(args.cpu_pairs):
+                oracle.farneback(host[t], host[t + 1], **{("iters" if k == "iterations" else k): v
+                                                          for k, v in params.items()})
+            cpu_s = time.perf_counter() - tc
+            out["cpu_baseline"] = {"value": round(args.cpu_pairs / cpu_s, 4), "unit": "frames/s", "cores": 1,
+                                   "kind": "port",
+                                   "sample": "%d 1080p frame pairs of the same clip, stateless two-image calls, "
+                                             "oracle/farneback_oracle.cpp -O3 single thread (%.1f s)"
+                                             % (args.cpu_pairs, cpu_s)}
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

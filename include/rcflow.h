@@ -76,8 +76,10 @@ const char* rcflow_last_error(void);
 /* Waits for everything enqueued on the slot. */
 int rcflow_sync(rc_ctx* ctx, int stream);
 /* Runs the slot on a caller-owned hipStream_t (e.g. the host framework's current
- * stream); NULL restores the slot's own stream. */
+ * stream; NULL is the device's null stream).  rcflow_use_own_stream restores the slot's
+ * own non-blocking stream. */
 int rcflow_set_hip_stream(rc_ctx* ctx, int stream, void* hip_stream);
+int rcflow_use_own_stream(rc_ctx* ctx, int stream);
 /* Tunables: "chunk" = frame pairs per launch in clip mode (default 4);
  * "exact_taps" = 1 keeps every polynomial-expansion tap instead of dropping taps whose
  * total weight is below 1e-9 of the kernel mass (default 0). */
@@ -137,6 +139,9 @@ int rcflow_analysis_reset(rc_ctx* ctx, int stream, int w, int h);
  * Adds this flow field's counts to the slot's cumulative histogram. */
 int rcflow_histogram_dev(rc_ctx* ctx, int stream, const float* d_flow_xy, size_t flow_step,
                          int w, int h);
+/* The same for `count` resident flow fields in one launch (a segment's flows). */
+int rcflow_histogram_clip_dev(rc_ctx* ctx, int stream, const float* d_flows_xy,
+                              size_t flow_frame_stride, size_t flow_step, int count, int w, int h);
 /* Replaces the threshold scans of create_histogram (ripcurrents_module.cpp:109-144):
  * derives UPPER, UPPER2d[36], prop_above_upper[36] on the device from the slot's counts. */
 int rcflow_thresholds_dev(rc_ctx* ctx, int stream);

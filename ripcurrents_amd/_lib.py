@@ -41,6 +41,7 @@ SIGNATURES = {
     "rcflow_last_error": [],
     "rcflow_sync": [_vp, _i],
     "rcflow_set_hip_stream": [_vp, _i, _vp],
+    "rcflow_use_own_stream": [_vp, _i],
     "rcflow_set_option": [_vp, C.c_char_p, _i],
     "rcflow_farneback_u8": [_vp, _i, _vp, _sz, _vp, _sz, _i, _i, _vp, _sz, _d, _i, _i, _i, _i, _d, _i],
     "rcflow_farneback_dev": [_vp, _i, _vp, _sz, _vp, _sz, _i, _i, _vp, _sz, _pp],
@@ -53,6 +54,7 @@ SIGNATURES = {
     "rcflow_stage_flow_iter_dev": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "rcflow_analysis_reset": [_vp, _i, _i, _i],
     "rcflow_histogram_dev": [_vp, _i, _vp, _sz, _i, _i],
+    "rcflow_histogram_clip_dev": [_vp, _i, _vp, _sz, _sz, _i, _i, _i],
     "rcflow_thresholds_dev": [_vp, _i],
     "rcflow_histogram_read": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rcflow_histogram_write": [_vp, _i, _vp],

@@ -60,6 +60,7 @@ class Context:
         check(self._lib.rcflow_create(C.byref(h), device, max_w, max_h, streams))
         self._h = h
         self.max_w, self.max_h = max_w, max_h
+        self._own, self._bound = set(), {}
 
     def close(self):
         if getattr(self, "_h", None):
@@ -85,10 +86,22 @@ class Context:
     def use_torch_stream(self, stream=0, torch_stream=None):
         """Run the slot on a torch stream (default: torch's current stream)."""
         ts = torch_stream if torch_stream is not None else torch.cuda.current_stream(self.device)
+        self._own.discard(stream)
+        self._bound[stream] = ts.cuda_stream
         check(self._lib.rcflow_set_hip_stream(self._h, stream, C.c_void_p(ts.cuda_stream)))
 
     def use_own_stream(self, stream=0):
-        check(self._lib.rcflow_set_hip_stream(self._h, stream, None))
+        self._own.add(stream)
+        check(self._lib.rcflow_use_own_stream(self._h, stream))
+
+    def _bind(self, stream):
+        """Device entry points run on torch's current stream (so tensor lifetimes and
+        torch.cuda events order against them) unless use_own_stream() was asked for."""
+        if stream not in self._own:
+            ts = torch.cuda.current_stream(self.device).cuda_stream
+            if self._bound.get(stream) != ts:
+                check(self._lib.rcflow_set_hip_stream(self._h, stream, C.c_void_p(ts)))
+                self._bound[stream] = ts
 
     def set_option(self, name, value):
         check(self._lib.rcflow_set_option(self._h, name.encode(), int(value)))
@@ -119,6 +132,7 @@ class Context:
             if flow is None:
                 flow = torch.empty((h, w, 2), dtype=torch.float32, device=prev.device)
             p = _params(pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags)
+            self._bind(stream)
             check(self._lib.rcflow_farneback_dev(
                 self._h, stream, self._ptr(prev), prev.stride(0), self._ptr(next), next.stride(0), w, h,
                 self._ptr(flow), flow.stride(0) * 4, C.byref(p)))
@@ -149,6 +163,7 @@ class Context:
                     kw.get("flags", 0))
         if flow is None:
             flow = torch.empty((h, w, 2), dtype=torch.float32, device=frame.device)
+        self._bind(stream)
         rc = check(self._lib.rcflow_push_frame_dev(self._h, stream, self._ptr(frame), frame.stride(0), w, h,
                                                    self._ptr(flow), flow.stride(0) * 4, C.byref(p)))
         return None if rc == 1 else flow
@@ -164,6 +179,7 @@ class Context:
         if flows is None:
             flows = torch.empty((T - 1, h, w, 2), dtype=torch.float32, device=frames.device)
         p = _params(pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags)
+        self._bind(stream)
         check(self._lib.rcflow_farneback_clip_dev(
             self._h, stream, self._ptr(frames), frames.stride(0), frames.stride(1), T, w, h,
             self._ptr(flows), flows.stride(0) * 4, flows.stride(1) * 4, C.byref(p)))
@@ -180,6 +196,7 @@ class Context:
         h, w = img.shape
         _, wk, hk = self.level_geometry(w, h, pyr_scale, 64, k)
         out = torch.empty((hk, wk), dtype=torch.float32, device=self.device)
+        self._bind(stream)
         check(self._lib.rcflow_stage_pyr_level_dev(self._h, stream, self._ptr(img), img.stride(0), w, h,
                                                    pyr_scale, k, self._ptr(out)))
         return out
@@ -188,6 +205,7 @@ class Context:
         I = self._dev(I, torch.float32).contiguous()
         h, w = I.shape
         R = torch.empty((h, w, 5), dtype=torch.float32, device=self.device)
+        self._bind(stream)
         check(self._lib.rcflow_stage_polyexp_dev(self._h, stream, self._ptr(I), w, h, poly_n, poly_sigma,
                                                  self._ptr(R)))
         return R
@@ -198,6 +216,7 @@ class Context:
         h, w = R0.shape[:2]
         fin = None if flow_in is None else self._dev(flow_in, torch.float32).contiguous()
         out = torch.empty((h, w, 2), dtype=torch.float32, device=self.device)
+        self._bind(stream)
         check(self._lib.rcflow_stage_flow_iter_dev(self._h, stream, self._ptr(R0), self._ptr(R1),
                                                    None if fin is None else self._ptr(fin), w, h, winsize,
                                                    flags, self._ptr(out)))
@@ -205,6 +224,7 @@ class Context:
 
     # ------------------------------------------------------------------ B: analysis
     def analysis_reset(self, w, h, stream=0):
+        self._bind(stream)
         check(self._lib.rcflow_analysis_reset(self._h, stream, w, h))
 
     def _flow(self, flow):
@@ -222,7 +242,9 @@ class Context:
         """
         flow = self._flow(current)
         h, w = flow.shape[:2]
+        self._bind(stream)
         check(self._lib.rcflow_histogram_dev(self._h, stream, self._ptr(flow), flow.stride(0) * 4, w, h))
+        self._bind(stream)
         check(self._lib.rcflow_thresholds_dev(self._h, stream))
         if st is not None:
             self.histogram_read(st, stream)
@@ -231,14 +253,24 @@ class Context:
     def histogram_accumulate(self, current, stream=0):
         flow = self._flow(current)
         h, w = flow.shape[:2]
+        self._bind(stream)
         check(self._lib.rcflow_histogram_dev(self._h, stream, self._ptr(flow), flow.stride(0) * 4, w, h))
 
+    def histogram_accumulate_clip(self, flows, stream=0):
+        """Counts of a whole segment's flow fields ([T,H,W,2]) in one launch."""
+        T, h, w = flows.shape[:3]
+        self._bind(stream)
+        check(self._lib.rcflow_histogram_clip_dev(self._h, stream, self._ptr(flows), flows.stride(0) * 4,
+                                                  flows.stride(1) * 4, T, w, h))
+
     def thresholds(self, stream=0):
+        self._bind(stream)
         check(self._lib.rcflow_thresholds_dev(self._h, stream))
 
     def histogram_read(self, st=None, stream=0):
         st = st or HistState()
         hs, up = C.c_int32(), C.c_float()
+        self._bind(stream)
         check(self._lib.rcflow_histogram_read(
             self._h, stream, st.hist.ctypes.data, st.hist2d.ctypes.data, C.addressof(hs),
             st.histsum2d.ctypes.data, C.addressof(up), st.UPPER2d.ctypes.data,
@@ -250,12 +282,14 @@ class Context:
         """The RC_HIST_WORDS int32 block as a CUDA tensor aliasing the slot's counters
         (what torch.distributed.all_reduce sums across ranks)."""
         p = C.c_void_p()
+        self._bind(stream)
         check(self._lib.rcflow_histogram_device_ptr(self._h, stream, C.byref(p)))
         return _alias_tensor(p.value, HIST_WORDS, torch.int32, self.device)
 
     def histogram_write(self, words, stream=0):
         words = np.ascontiguousarray(words, np.int32)
         assert words.size == HIST_WORDS
+        self._bind(stream)
         check(self._lib.rcflow_histogram_write(self._h, stream, words.ctypes.data))
 
     def create_flow_accumulate(self, current, framecount, MID=0.5, LOWER=0.2, want=("polar", "waterclass",
@@ -274,6 +308,7 @@ class Context:
         wp, ws = mk("waterclass", (h, w, 3), torch.float32)
         op, os_ = mk("out", (h, w, 3), torch.float32)
         mp, ms = mk("outmask", (h, w), torch.uint8)
+        self._bind(stream)
         check(self._lib.rcflow_classify_accumulate_dev(
             self._h, stream, self._ptr(flow), flow.stride(0) * 4, w, h, framecount, MID, LOWER, pp, ps, wp, ws,
             op, os_, mp, ms))
@@ -281,6 +316,7 @@ class Context:
 
     def accumulator(self, w, h, stream=0):
         acc = np.empty((h, w), np.float32)
+        self._bind(stream)
         check(self._lib.rcflow_accumulator_read(self._h, stream, acc.ctypes.data))
         return acc
 
@@ -288,12 +324,14 @@ class Context:
         """streamlines_mat.forEach(streamline_field(...)) ripcurrents.cpp:229-231; state in the slot."""
         flow = self._flow(flow)
         h, w = flow.shape[:2]
+        self._bind(stream)
         check(self._lib.rcflow_advect_field_dev(self._h, stream, self._ptr(flow), flow.stride(0) * 4, w, h, dt,
                                                 iterations, UPPER))
 
     def streamline_field_state(self, w, h, stream=0):
         pt = np.empty((h, w, 2), np.float32)
         dist = np.empty((h, w), np.float32)
+        self._bind(stream)
         check(self._lib.rcflow_advect_field_read(self._h, stream, pt.ctypes.data, dist.ctypes.data))
         return pt, dist
 
@@ -306,6 +344,7 @@ class Context:
         n = d_pts.shape[0]
         iters = 100 if variant == 2 else iterations
         tr = torch.zeros((n, iters, 2), dtype=torch.float32, device=self.device) if trace else None
+        self._bind(stream)
         check(self._lib.rcflow_advect_points_dev(
             self._h, stream, self._ptr(d_pts), n, self._ptr(flow), flow.stride(0) * 4, w, h, dt, iterations,
             UPPER, variant, None if tr is None else self._ptr(tr)))
@@ -315,6 +354,7 @@ class Context:
         flow = self._flow(flow)
         h, w = flow.shape[:2]
         pt = self._dev(pt, torch.float32).contiguous()
+        self._bind(stream)
         check(self._lib.rcflow_get_delta_field_dev(self._h, stream, self._ptr(pt), pt.stride(0) * 4,
                                                    self._ptr(flow), flow.stride(0) * 4, w, h, dt, UPPER))
         return pt
@@ -322,6 +362,7 @@ class Context:
     def _postop(self, fn, current, stream):
         flow = self._flow(current)
         h, w = flow.shape[:2]
+        self._bind(stream)
         check(fn(self._h, stream, self._ptr(flow), flow.stride(0) * 4, w, h))
         return flow
 
@@ -335,6 +376,7 @@ class Context:
         return self._postop(self._lib.rcflow_stabilizer_dev, current, stream)
 
     def window_mean(self, avg, slot, cur, window, stream=0):
+        self._bind(stream)
         check(self._lib.rcflow_window_mean_dev(self._h, stream, self._ptr(avg), self._ptr(slot), self._ptr(cur),
                                                avg.numel(), window))
 
@@ -343,6 +385,7 @@ class Context:
         h, w = flow.shape[:2]
         hsv = torch.zeros((h, w, 3), dtype=torch.uint8, device=self.device)
         md = C.c_float(max_displacement)
+        self._bind(stream)
         check(self._lib.rcflow_vector_to_color_dev(self._h, stream, self._ptr(flow), flow.stride(0) * 4, w, h,
                                                    self._ptr(hsv), hsv.stride(0), C.byref(md)))
         return hsv, md.value
@@ -353,6 +396,7 @@ class Context:
         if hsv is None:
             hsv = torch.zeros((h, w, 3), dtype=torch.uint8, device=self.device)
         mf = C.c_float(max_frobenius)
+        self._bind(stream)
         check(self._lib.rcflow_shear_rate_to_color_dev(self._h, stream, self._ptr(flow), flow.stride(0) * 4, w, h,
                                                        self._ptr(hsv), hsv.stride(0), C.byref(mf)))
         return hsv, mf.value

@@ -59,54 +59,112 @@ __device__ __forceinline__ const float2* rc_row2(const float* base, size_t step,
 }
 
 // ============================================================================ B1+B2 histogram
-// One LDS atomic per pixel on a block-private hist2d[36][50]; hist, histsum and histsum2d
-// are its marginals and are formed when the block flushes.
-__global__ __launch_bounds__(RC_BLOCK) void k_polar_hist(const float* flow, size_t step, int w, int h,
-                                                         int* words) {
+// Block-private hist2d[36][50] in LDS; hist, histsum and histsum2d are its marginals and
+// are formed when the block flushes.  Flow fields are smooth, so most lanes of a wave
+// fall into a handful of bins: lanes are grouped by key with ballots and each group
+// costs one LDS atomic (added with the group's population count).
+#define RC_HIST_COPIES 16
+__device__ __forceinline__ void rc_hist_add(int* lh, int key) {
+    // Peel off the two most popular keys of the wave with scalar control flow (ballot masks
+    // in SGPRs, the leader's key by v_readlane): smooth fields put most lanes there.  What
+    // is left takes plain per-lane LDS atomics (distinct keys do not conflict).
+    unsigned long long todo = __ballot(key >= 0);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+        if (!todo) break;
+        int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+        int k = __builtin_amdgcn_readlane(key, leader);
+        unsigned long long same = __ballot(key == k);
+        if (lane == leader) atomicAdd(&lh[k], __popcll(same));
+        if (key == k) key = -1;
+        todo &= ~same;
+    }
+    if (key >= 0) atomicAdd(&lh[key], 1);
+}
+
+__device__ __forceinline__ int rc_hist_key(float2 f) {
+    float mag = sqrtf(f.x * f.x + f.y * f.y);
+    int bin = (int)(mag * RC_HIST_RESOLUTION);
+    if (!(bin < RC_HIST_BINS && bin >= 0)) return -1;
+    return rc_dir_index(rc_fast_atan2_deg(f.y, f.x)) * RC_HIST_BINS + bin;
+}
+
+__global__ __launch_bounds__(RC_BLOCK) void k_polar_hist(const float* flow0, size_t frame_stride, size_t step,
+                                                         int w, int h, int* parts) {
     __shared__ int lh[RC_HIST_DIRECTIONS * RC_HIST_BINS];
+    const float* flow = (const float*)((const char*)flow0 + (size_t)blockIdx.y * frame_stride);
     for (int i = threadIdx.x; i < RC_HIST_DIRECTIONS * RC_HIST_BINS; i += RC_BLOCK) lh[i] = 0;
     __syncthreads();
     const int w2 = (w + 1) >> 1;
     const long long total = (long long)w2 * h;
-    for (long long i = (long long)blockIdx.x * RC_BLOCK + threadIdx.x; i < total;
-         i += (long long)gridDim.x * RC_BLOCK) {
-        int y = (int)(i / w2), x = (int)(i - (long long)y * w2) * 2;
-        const float2* r = rc_row2(flow, step, y);
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            if (x + q < w) {
-                float2 f = r[x + q];
-                float mag = sqrtf(f.x * f.x + f.y * f.y);
-                int bin = (int)(mag * RC_HIST_RESOLUTION);
-                if (bin < RC_HIST_BINS && bin >= 0) {
-                    int dir = rc_dir_index(rc_fast_atan2_deg(f.y, f.x));
-                    atomicAdd(&lh[dir * RC_HIST_BINS + bin], 1);
-                }
+    const long long span = (long long)gridDim.x * RC_BLOCK;
+    // every lane runs the same number of rounds so the ballots see whole waves
+    const long long rounds = (total + span - 1) / span;
+    for (long long it = 0; it < rounds; it++) {
+        long long i = it * span + (long long)blockIdx.x * RC_BLOCK + threadIdx.x;
+        int k0 = -1, k1 = -1;
+        if (i < total) {
+            int y = (int)(i / w2), x = (int)(i - (long long)y * w2) * 2;
+            const float2* r = rc_row2(flow, step, y) + x;
+            if (x + 1 < w && (((size_t)r) & 15) == 0) {
+                float4 v = *(const float4*)r;
+                k0 = rc_hist_key(make_float2(v.x, v.y));
+                k1 = rc_hist_key(make_float2(v.z, v.w));
+            } else {
+                k0 = rc_hist_key(r[0]);
+                if (x + 1 < w) k1 = rc_hist_key(r[1]);
             }
+        }
+        rc_hist_add(lh, k0);
+        rc_hist_add(lh, k1);
+    }
+    __syncthreads();
+    // flush into one of RC_HIST_COPIES partial tables: blocks that share a table queue on
+    // the same addresses, so the copies keep those chains short
+    int* part = parts + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) % RC_HIST_COPIES) *
+                            (RC_HIST_DIRECTIONS * RC_HIST_BINS);
+    for (int i = threadIdx.x; i < RC_HIST_DIRECTIONS * RC_HIST_BINS; i += RC_BLOCK) {
+        int v = lh[i];
+        if (v) atomicAdd(&part[i], v);
+    }
+}
+
+// Folds (and clears) the partial tables into the slot's cumulative counters
+// words = hist[50] | hist2d[1800] | histsum | histsum2d[36]; hist, histsum and histsum2d
+// are the marginals of hist2d (ripcurrents_module.cpp:102-104 increments all four together).
+__global__ __launch_bounds__(RC_BLOCK) void k_hist_fold(int* parts, int* words) {
+    __shared__ int lbin[RC_HIST_BINS], ldir[RC_HIST_DIRECTIONS], ltot;
+    if (threadIdx.x < RC_HIST_BINS) lbin[threadIdx.x] = 0;
+    if (threadIdx.x < RC_HIST_DIRECTIONS) ldir[threadIdx.x] = 0;
+    if (threadIdx.x == 0) ltot = 0;
+    __syncthreads();
+    const int i = blockIdx.x * RC_BLOCK + threadIdx.x;
+    int v = 0;
+    if (i < RC_HIST_DIRECTIONS * RC_HIST_BINS) {
+        int t[RC_HIST_COPIES];
+#pragma unroll
+        for (int c = 0; c < RC_HIST_COPIES; c++) t[c] = parts[c * (RC_HIST_DIRECTIONS * RC_HIST_BINS) + i];
+#pragma unroll
+        for (int c = 0; c < RC_HIST_COPIES; c++) {
+            v += t[c];
+            if (t[c]) parts[c * (RC_HIST_DIRECTIONS * RC_HIST_BINS) + i] = 0;
+        }
+        if (v) {
+            words[RC_HIST_BINS + i] += v;
+            atomicAdd(&lbin[i % RC_HIST_BINS], v);
+            atomicAdd(&ldir[i / RC_HIST_BINS], v);
+            atomicAdd(&ltot, v);
         }
     }
     __syncthreads();
-    // words: hist[50] | hist2d[1800] | histsum | histsum2d[36]
     int* hist = words;
-    int* hist2d = words + RC_HIST_BINS;
-    int* histsum = hist2d + RC_HIST_DIRECTIONS * RC_HIST_BINS;
+    int* histsum = words + RC_HIST_BINS + RC_HIST_DIRECTIONS * RC_HIST_BINS;
     int* histsum2d = histsum + 1;
-    for (int i = threadIdx.x; i < RC_HIST_DIRECTIONS * RC_HIST_BINS; i += RC_BLOCK) {
-        int v = lh[i];
-        if (v) atomicAdd(&hist2d[i], v);
-    }
-    if (threadIdx.x < RC_HIST_BINS) {
-        int v = 0;
-        for (int d = 0; d < RC_HIST_DIRECTIONS; d++) v += lh[d * RC_HIST_BINS + threadIdx.x];
-        if (v) atomicAdd(&hist[threadIdx.x], v);
-    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + RC_HIST_DIRECTIONS) {
-        int d = threadIdx.x - 64, v = 0;
-        for (int b = 0; b < RC_HIST_BINS; b++) v += lh[d * RC_HIST_BINS + b];
-        if (v) {
-            atomicAdd(&histsum2d[d], v);
-            atomicAdd(histsum, v);
-        }
-    }
+    if (threadIdx.x < RC_HIST_BINS && lbin[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lbin[threadIdx.x]);
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + RC_HIST_DIRECTIONS && ldir[threadIdx.x - 64])
+        atomicAdd(&histsum2d[threadIdx.x - 64], ldir[threadIdx.x - 64]);
+    if (threadIdx.x == 128 && ltot) atomicAdd(histsum, ltot);
 }
 
 // Threshold scans, ripcurrents_module.cpp:109-144, one lane per direction.
@@ -457,6 +515,7 @@ static int analysis_ensure(rc_ctx* ctx, RcSlot& s, int w, int h, bool reset) {
     size_t n = (size_t)w * h;
     int rc;
     if ((rc = rc_buf_ensure(an.hist, RC_HIST_WORDS * sizeof(int)))) return rc;
+    if ((rc = rc_buf_ensure(an.hist_part, RC_HIST_COPIES * RC_HIST_DIRECTIONS * RC_HIST_BINS * sizeof(int)))) return rc;
     if ((rc = rc_buf_ensure(an.thr, (THR_WORDS + 3) * sizeof(float)))) return rc;
     if ((rc = rc_buf_ensure(an.acc, n * sizeof(float)))) return rc;
     if ((rc = rc_buf_ensure(an.pt, n * sizeof(float2)))) return rc;
@@ -464,6 +523,7 @@ static int analysis_ensure(rc_ctx* ctx, RcSlot& s, int w, int h, bool reset) {
     if ((rc = rc_buf_ensure(an.scratch, (4 * 2048 + 8) * sizeof(double)))) return rc;
     an.w = w; an.h = h;
     RC_HIP(hipMemsetAsync(an.hist.p, 0, RC_HIST_WORDS * sizeof(int), s.cur));
+    RC_HIP(hipMemsetAsync(an.hist_part.p, 0, RC_HIST_COPIES * RC_HIST_DIRECTIONS * RC_HIST_BINS * sizeof(int), s.cur));
     RC_HIP(hipMemsetAsync(an.acc.p, 0, n * sizeof(float), s.cur));
     RC_HIP(hipMemsetAsync(an.pt.p, 0, n * sizeof(float2), s.cur));
     RC_HIP(hipMemsetAsync(an.dist.p, 0, n * sizeof(float), s.cur));
@@ -490,20 +550,34 @@ static int check_flow(const float* d_flow, size_t step, int w, int h) {
     return RC_OK;
 }
 
-extern "C" int rcflow_histogram_dev(rc_ctx* ctx, int stream, const float* d_flow, size_t flow_step, int w, int h) {
+extern "C" int rcflow_histogram_clip_dev(rc_ctx* ctx, int stream, const float* d_flows, size_t flow_frame_stride,
+                                         size_t flow_step, int count, int w, int h) {
     RcSlot* s = rc_slot(ctx, stream);
     if (!s) return RC_EINVAL;
-    int rc = check_flow(d_flow, flow_step, w, h);
+    int rc = check_flow(d_flows, flow_step, w, h);
     if (rc) return rc;
+    if (count < 1 || count > 65535 || (count > 1 && flow_frame_stride < flow_step * (size_t)(h - 1) + (size_t)w * 8))
+        return RC_EINVAL;
     RC_HIP(hipSetDevice(ctx->device));
     if ((rc = analysis_ensure(ctx, *s, w, h, false))) return rc;
     {
-        RcProfScope ps(ctx, s->cur, RC_K_HIST, 0, 8. * w * h);
-        hipLaunchKernelGGL(k_polar_hist, dim3(grid_for(((long long)(w + 1) / 2) * h)), dim3(RC_BLOCK), 0, s->cur,
-                           d_flow, flow_step, w, h, (int*)s->an.hist.p);
+        RcProfScope ps(ctx, s->cur, RC_K_HIST, 0, 8. * w * h * count);
+        long long per_frame = ((long long)(w + 1) / 2) * h;
+        int nb = grid_for(per_frame);
+        int cap = 2048 / count;       // about 8 blocks per CU over the whole launch
+        if (cap < 8) cap = 8;
+        if (nb > cap) nb = cap;
+        hipLaunchKernelGGL(k_polar_hist, dim3(nb, count), dim3(RC_BLOCK), 0, s->cur, d_flows, flow_frame_stride,
+                           flow_step, w, h, (int*)s->an.hist_part.p);
+        hipLaunchKernelGGL(k_hist_fold, dim3((RC_HIST_DIRECTIONS * RC_HIST_BINS + RC_BLOCK - 1) / RC_BLOCK),
+                           dim3(RC_BLOCK), 0, s->cur, (int*)s->an.hist_part.p, (int*)s->an.hist.p);
     }
     RC_HIP(hipGetLastError());
     return RC_OK;
+}
+
+extern "C" int rcflow_histogram_dev(rc_ctx* ctx, int stream, const float* d_flow, size_t flow_step, int w, int h) {
+    return rcflow_histogram_clip_dev(ctx, stream, d_flow, 0, flow_step, 1, w, h);
 }
 
 extern "C" int rcflow_thresholds_dev(rc_ctx* ctx, int stream) {

@@ -1,0 +1,517 @@
+// flow_iter_kernels.hip -- the fused Farneback iteration kernel (SURVEY.md section 8(a) rows
+// A3 FarnebackUpdateMatrices, A4/A5 FarnebackUpdateFlow_Blur/_GaussianBlur, A6 stripe
+// logic; call site RipCurrents_main/ripcurrents.cpp:215):
+//
+//     flow_out = solve( window( M( R0, R1 sampled at p + flow_in, flow_in ) ) )
+//
+// The 5-channel matrix image M of the upstream algorithm never goes to HBM: a block
+// evaluates it for its tile plus the window halo straight into LDS (clamped coordinates =
+// the replicate border of the window), applies the separable window there and solves the
+// 2x2 system in double like upstream.  Upstream's in-loop stripe update (A6) equals
+// "window+solve the whole image, then update all matrices" (tests/test_oracle.py pins
+// that), so one launch of this kernel is one iteration and the intermediate flow of
+// iteration i only exists as this kernel's input for iteration i+1.
+//
+// HBM traffic per pixel: R0 20 B + R1 20 B (gathered; L2 serves the 4x bilinear overlap)
+// + flow_in 8 B (2 B when it is the coarser level, 0 at the coarsest) + flow_out 8 B.
+//
+// Compile-time tile/window instantiations cover the reference's window sizes (3, 5, 10,
+// 20: SURVEY.md section 2.2); any other winsize takes the generic runtime kernel.
+
+#include "rc_device.h"
+
+#define RC_ITER_BATCH 3
+
+// resize(prevFlow, INTER_LINEAR) then flow *= 1/pyr_scale (optflow.cpp calc()), or the
+// same-resolution flow of the previous iteration, or zeros at the coarsest scale.
+__device__ __forceinline__ float2 rc_flow_in(const RcIterArgs& a, const float2* fin, int gx, int gy) {
+    if (a.in_mode == 0) return make_float2(0.f, 0.f);
+    if (a.in_mode == 1) return fin[(size_t)gy * a.w + gx];
+    float ax, ay;
+    int sx = rc_src_x(gx, a.up_scale_x, a.fin_w, ax);
+    int sx1 = min(sx + 1, a.fin_w - 1);
+    int sy = rc_src_y(gy, a.up_scale_y, ay);
+    int sy0 = rc_clampi(sy, 0, a.fin_h - 1), sy1 = rc_clampi(sy + 1, 0, a.fin_h - 1);
+    const float2* S0 = fin + (size_t)sy0 * a.fin_w;
+    const float2* S1 = fin + (size_t)sy1 * a.fin_w;
+    float2 p00 = S0[sx], p01 = S0[sx1], p10 = S1[sx], p11 = S1[sx1];
+    float a0 = 1.f - ax, a1 = ax, b0 = 1.f - ay, b1 = ay;
+    float r0x = p00.x * a0 + p01.x * a1, r1x = p10.x * a0 + p11.x * a1;
+    float r0y = p00.y * a0 + p01.y * a1, r1y = p10.y * a0 + p11.y * a1;
+    float2 v;
+    v.x = (r0x * b0 + r1x * b1) * a.up_mul;
+    v.y = (r0y * b0 + r1y * b1) * a.up_mul;
+    return v;
+}
+
+// FarnebackUpdateMatrices for one pixel (operation order of optflow.cpp kept; built with
+// -ffp-contract=off so nothing here fuses).
+struct RcM5 { float m0, m1, m2, m3, m4; };
+
+__device__ __forceinline__ RcM5 rc_matrices(const float4* __restrict__ RA0, const float* __restrict__ RB0,
+                                            const float4* __restrict__ RA1, const float* __restrict__ RB1,
+                                            int gx, int gy, int w, int h, float dx, float dy) {
+    float fx = gx + dx, fy = gy + dy;
+    int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    fx -= x1;
+    fy -= y1;
+    size_t p0 = (size_t)gy * w + gx;
+    float4 A0 = RA0[p0];
+    float B0 = RB0[p0];
+    // Branch-free: the four texels are always fetched (from a safe address when the sample
+    // falls outside) and the out-of-range case is a select, so a thread's gathers for several
+    // pixels can all be in flight together.
+    const bool inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+    const size_t p = inside ? (size_t)y1 * w + x1 : p0;
+    const size_t pw = inside ? (size_t)w : 0, p1 = inside ? 1 : 0;
+    float4 q00 = RA1[p], q01 = RA1[p + p1], q10 = RA1[p + pw], q11 = RA1[p + pw + p1];
+    float e00 = RB1[p], e01 = RB1[p + p1], e10 = RB1[p + pw], e11 = RB1[p + pw + p1];
+    float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy);
+    float a10 = (1.f - fx) * fy, a11 = fx * fy;
+    float r2 = a00 * q00.x + a01 * q01.x + a10 * q10.x + a11 * q11.x;
+    float r3 = a00 * q00.y + a01 * q01.y + a10 * q10.y + a11 * q11.y;
+    float r4 = a00 * q00.z + a01 * q01.z + a10 * q10.z + a11 * q11.z;
+    float r5 = a00 * q00.w + a01 * q01.w + a10 * q10.w + a11 * q11.w;
+    float r6 = a00 * e00 + a01 * e01 + a10 * e10 + a11 * e11;
+    r4 = (A0.z + r4) * 0.5f;
+    r5 = (A0.w + r5) * 0.5f;
+    r6 = (B0 + r6) * 0.25f;
+    if (!inside) {
+        r2 = r3 = 0.f;
+        r4 = A0.z;
+        r5 = A0.w;
+        r6 = B0 * 0.5f;
+    }
+    r2 = (A0.x - r2) * 0.5f;
+    r3 = (A0.y - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    if ((unsigned)(gx - 5) >= (unsigned)(w - 10) || (unsigned)(gy - 5) >= (unsigned)(h - 10)) {
+        // border[5] = {0.14, 0.14, 0.4472, 0.4472, 0.4472}, product over the x and y sides
+        float bl = gx < 5 ? (gx < 2 ? 0.14f : 0.4472f) : 1.f;
+        int rx = w - gx - 1;
+        float br = gx >= w - 5 ? (rx < 2 ? 0.14f : 0.4472f) : 1.f;
+        float bt = gy < 5 ? (gy < 2 ? 0.14f : 0.4472f) : 1.f;
+        int ry = h - gy - 1;
+        float bb = gy >= h - 5 ? (ry < 2 ? 0.14f : 0.4472f) : 1.f;
+        float scale = bl * br * bt * bb;
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
+    RcM5 o;
+    o.m0 = r4 * r4 + r6 * r6;      // G(1,1)
+    o.m1 = (r4 + r5) * r6;         // G(1,2)
+    o.m2 = r5 * r5 + r6 * r6;      // G(2,2)
+    o.m3 = r4 * r2 + r6 * r3;      // h(1)
+    o.m4 = r6 * r2 + r5 * r3;      // h(2)
+    return o;
+}
+
+__device__ __forceinline__ float2 rc_solve(const double* g) {
+    double idet = 1. / (g[0] * g[2] - g[1] * g[1] + 1e-3);
+    float2 f;
+    f.x = (float)((g[0] * g[4] - g[1] * g[3]) * idet);
+    f.y = (float)((g[2] * g[3] - g[1] * g[4]) * idet);
+    return f;
+}
+
+// TW, TH, M compile-time (TW = TH = 0: runtime values from the arguments).
+template <int TW_, int TH_, int M_, int GAUSS_>
+__global__ __launch_bounds__(RC_BLOCK) void k_flow_iter(RcIterArgs a) {
+    extern __shared__ __align__(16) float smf[];
+    constexpr bool RT = (TW_ == 0);
+    const int tw = RT ? a.tw : TW_, th = RT ? a.th : TH_, m = RT ? a.win.m : M_;
+    const bool gauss = RT ? (a.win.gaussian != 0) : (GAUSS_ != 0);
+    const int tid = threadIdx.x;
+    const int z = blockIdx.y;
+    const int t = rc_xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y);
+    const int tx0 = (t % a.tiles_x) * tw, ty0 = (t / a.tiles_x) * th;
+    const int w = a.w, h = a.h;
+    const int MW = tw + 2 * m, MH = th + 2 * m, MP = MW | 1;
+    float* Ms = smf;                    // [5][MH][MP]
+
+    const size_t s0 = (size_t)((a.slot0 + z) % a.nslots) * a.R_slot_stride;
+    const size_t s1 = (size_t)((a.slot1 + z) % a.nslots) * a.R_slot_stride;
+    const float4* RA0 = a.RA + s0;  const float* RB0 = a.RB + s0;
+    const float4* RA1 = a.RA + s1;  const float* RB1 = a.RB + s1;
+    const float2* fin = a.fin ? a.fin + (size_t)z * a.fin_pair_stride : nullptr;
+    char* fout = a.fout + (size_t)z * a.fout_pair_stride;
+
+    if (!a.solve) {   // iterations == 0: the flow is the (up-sampled) initial flow
+        for (int idx = tid; idx < tw * th; idx += RC_BLOCK) {
+            int gx = tx0 + idx % tw, gy = ty0 + idx / tw;
+            if (gx < w && gy < h)
+                *(float2*)(fout + (size_t)gy * a.fout_step + (size_t)gx * 8) = rc_flow_in(a, fin, gx, gy);
+        }
+        return;
+    }
+
+    // ---- phase 1: matrices for tile + halo -> LDS.  Items are taken RC_ITER_BATCH at a
+    // time so that a thread has that many flow loads, then that many gathers, in flight
+    // (the gather address depends on the flow: two HBM round trips per item otherwise).
+    for (int base = tid; base < MW * MH; base += RC_BLOCK * RC_ITER_BATCH) {
+        float2 d[RC_ITER_BATCH];
+        int gxs[RC_ITER_BATCH], gys[RC_ITER_BATCH];
+#pragma unroll
+        for (int q = 0; q < RC_ITER_BATCH; q++) {
+            int idx = min(base + q * RC_BLOCK, MW * MH - 1);
+            int ly = idx / MW, lx = idx - ly * MW;
+            gxs[q] = rc_clampi(tx0 - m + lx, 0, w - 1);
+            gys[q] = rc_clampi(ty0 - m + ly, 0, h - 1);
+            d[q] = rc_flow_in(a, fin, gxs[q], gys[q]);
+        }
+        RcM5 v[RC_ITER_BATCH];
+#pragma unroll
+        for (int q = 0; q < RC_ITER_BATCH; q++)
+            v[q] = rc_matrices(RA0, RB0, RA1, RB1, gxs[q], gys[q], w, h, d[q].x, d[q].y);
+#pragma unroll
+        for (int q = 0; q < RC_ITER_BATCH; q++) {
+            int idx = base + q * RC_BLOCK;
+            if (idx < MW * MH) {
+                int ly = idx / MW, lx = idx - ly * MW;
+                float* mp = Ms + ly * MP + lx;
+                mp[0] = v[q].m0;
+                mp[MH * MP] = v[q].m1;
+                mp[2 * MH * MP] = v[q].m2;
+                mp[3 * MH * MP] = v[q].m3;
+                mp[4 * MH * MP] = v[q].m4;
+            }
+        }
+    }
+    __syncthreads();
+
+    if constexpr (!RT && M_ == 1) {
+        // ---- small window: each thread owns one column and RPT rows; the vertical sums of
+        // its 2M+1 columns stay in registers (no second LDS buffer, no second barrier).
+        constexpr int RPT = TH_ / (RC_BLOCK / TW_);
+        constexpr int NC = 2 * M_ + 1;
+        const int lx = tid % TW_, r0 = (tid / TW_) * RPT;
+        const int gx = tx0 + lx;
+        double g[RPT][5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const float* mc = Ms + c * MH * MP + r0 * MP + lx;
+            float col[NC][RPT + 2 * M_];
+#pragma unroll
+            for (int j = 0; j < NC; j++)
+#pragma unroll
+                for (int r = 0; r < RPT + 2 * M_; r++) col[j][r] = mc[r * MP + j];
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                float v[NC];
+#pragma unroll
+                for (int j = 0; j < NC; j++) {
+                    if (GAUSS_) {
+                        float s = col[j][r + M_] * a.win.k[0];
+#pragma unroll
+                        for (int i = 1; i <= M_; i++) s += (col[j][r + M_ + i] + col[j][r + M_ - i]) * a.win.k[i];
+                        v[j] = s;
+                    } else {
+                        float s = col[j][r + M_];
+#pragma unroll
+                        for (int i = 1; i <= M_; i++) s += col[j][r + M_ + i] + col[j][r + M_ - i];
+                        v[j] = s;
+                    }
+                }
+                if (GAUSS_) {
+                    float s = v[M_] * a.win.k[0];
+#pragma unroll
+                    for (int i = 1; i <= M_; i++) s += a.win.k[i] * (v[M_ - i] + v[M_ + i]);
+                    g[r][c] = s;
+                } else {
+                    double s = v[M_];
+#pragma unroll
+                    for (int i = 1; i <= M_; i++) s += (double)v[M_ + i] + (double)v[M_ - i];
+                    g[r][c] = s * a.win.box_scale;
+                }
+            }
+        }
+        if (gx < w) {
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                int gy = ty0 + r0 + r;
+                if (gy < h) *(float2*)(fout + (size_t)gy * a.fout_step + (size_t)gx * 8) = rc_solve(g[r]);
+            }
+        }
+    } else {
+        // ---- large window: separable through a second LDS buffer
+        float* Vs = smf + 5 * MH * MP;      // [5][th][MP]
+        for (int idx = tid; idx < 5 * th * MW; idx += RC_BLOCK) {
+            int c = idx / (th * MW), rem = idx - c * (th * MW);
+            int o = rem / MW, col = rem - o * MW;
+            const float* mc = Ms + c * MH * MP + (o + m) * MP + col;
+            float s;
+            if (gauss) {
+                s = mc[0] * a.win.k[0];
+                for (int i = 1; i <= m; i++) s += (mc[i * MP] + mc[-i * MP]) * a.win.k[i];
+            } else {
+                s = mc[0];
+                for (int i = 1; i <= m; i++) s += mc[i * MP] + mc[-i * MP];
+            }
+            Vs[c * th * MP + o * MP + col] = s;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < tw * th; idx += RC_BLOCK) {
+            int o = idx / tw, lx = idx - o * tw;
+            int gx = tx0 + lx, gy = ty0 + o;
+            if (gx >= w || gy >= h) continue;
+            double g[5];
+            const float* vc = Vs + o * MP + lx + m;
+            if (gauss) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    const float* v = vc + c * th * MP;
+                    float s = v[0] * a.win.k[0];
+                    for (int i = 1; i <= m; i++) s += a.win.k[i] * (v[-i] + v[i]);
+                    g[c] = s;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    const float* v = vc + c * th * MP;
+                    double s = v[0];
+                    for (int i = 1; i <= m; i++) s += (double)v[i] + (double)v[-i];
+                    g[c] = s * a.win.box_scale;
+                }
+            }
+            *(float2*)(fout + (size_t)gy * a.fout_step + (size_t)gx * 8) = rc_solve(g);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// The 3x3-window kernel (winsize 3: ripcurrents.cpp:215, main.cpp:264): 64x16 tile,
+// 512 threads.  Latency is what bounds this stage, so the memory phases are explicit: every
+// thread first has the flow of its (at most three) tile+halo pixels in flight, then all
+// their polynomial gathers (8 x 16 B + 8 x 4 B + ... per pixel), and only then computes.
+// IN_MODE is a template parameter so that no control flow separates the loads.
+#define RC_W3_THREADS 512
+template <int IN_MODE, int GAUSS_>
+__global__ __launch_bounds__(RC_W3_THREADS) void k_flow_iter_w3(RcIterArgs a) {
+    constexpr int TW = 64, TH = 16, MW = TW + 2, MH = TH + 2, MP = MW | 1;
+    constexpr int NITEMS = MW * MH, NIT = (NITEMS + RC_W3_THREADS - 1) / RC_W3_THREADS;
+    extern __shared__ __align__(16) float smf[];
+    float* Ms = smf;                    // [5][MH][MP]
+    const int tid = threadIdx.x;
+    const int z = blockIdx.y;
+    const int t = rc_xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y);
+    const int tx0 = (t % a.tiles_x) * TW, ty0 = (t / a.tiles_x) * TH;
+    const int w = a.w, h = a.h;
+    const size_t s0 = (size_t)((a.slot0 + z) % a.nslots) * a.R_slot_stride;
+    const size_t s1 = (size_t)((a.slot1 + z) % a.nslots) * a.R_slot_stride;
+    const float4* __restrict__ RA0 = a.RA + s0;  const float* __restrict__ RB0 = a.RB + s0;
+    const float4* __restrict__ RA1 = a.RA + s1;  const float* __restrict__ RB1 = a.RB + s1;
+    const float2* __restrict__ fin = a.fin + (size_t)z * a.fin_pair_stride;
+    char* fout = a.fout + (size_t)z * a.fout_pair_stride;
+
+    int gx[NIT], gy[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; q++) {
+        int idx = min(tid + q * RC_W3_THREADS, NITEMS - 1);
+        int ly = idx / MW, lx = idx - ly * MW;
+        gx[q] = rc_clampi(tx0 - 1 + lx, 0, w - 1);
+        gy[q] = rc_clampi(ty0 - 1 + ly, 0, h - 1);
+    }
+    // ---- flow_in: all loads, then the arithmetic
+    float dx[NIT], dy[NIT];
+    if constexpr (IN_MODE == 0) {
+#pragma unroll
+        for (int q = 0; q < NIT; q++) dx[q] = dy[q] = 0.f;
+    } else if constexpr (IN_MODE == 1) {
+        float2 d[NIT];
+#pragma unroll
+        for (int q = 0; q < NIT; q++) d[q] = fin[(size_t)gy[q] * w + gx[q]];
+#pragma unroll
+        for (int q = 0; q < NIT; q++) { dx[q] = d[q].x; dy[q] = d[q].y; }
+    } else {
+        float2 p00[NIT], p01[NIT], p10[NIT], p11[NIT];
+        float ax[NIT], ay[NIT];
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            int sx = rc_src_x(gx[q], a.up_scale_x, a.fin_w, ax[q]);
+            int sx1 = min(sx + 1, a.fin_w - 1);
+            int sy = rc_src_y(gy[q], a.up_scale_y, ay[q]);
+            int sy0 = rc_clampi(sy, 0, a.fin_h - 1), sy1 = rc_clampi(sy + 1, 0, a.fin_h - 1);
+            const float2* S0 = fin + (size_t)sy0 * a.fin_w;
+            const float2* S1 = fin + (size_t)sy1 * a.fin_w;
+            p00[q] = S0[sx]; p01[q] = S0[sx1]; p10[q] = S1[sx]; p11[q] = S1[sx1];
+        }
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            float a0 = 1.f - ax[q], a1 = ax[q], b0 = 1.f - ay[q], b1 = ay[q];
+            float r0x = p00[q].x * a0 + p01[q].x * a1, r1x = p10[q].x * a0 + p11[q].x * a1;
+            float r0y = p00[q].y * a0 + p01[q].y * a1, r1y = p10[q].y * a0 + p11[q].y * a1;
+            dx[q] = (r0x * b0 + r1x * b1) * a.up_mul;
+            dy[q] = (r0y * b0 + r1y * b1) * a.up_mul;
+        }
+    }
+    // ---- polynomial coefficients: all gathers in flight
+    float4 A0[NIT], q00[NIT], q01[NIT], q10[NIT], q11[NIT];
+    float B0[NIT], e00[NIT], e01[NIT], e10[NIT], e11[NIT];
+    float fxs[NIT], fys[NIT];
+    bool inside[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; q++) {
+        float fx = gx[q] + dx[q], fy = gy[q] + dy[q];
+        int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+        fxs[q] = fx - x1;
+        fys[q] = fy - y1;
+        size_t p0 = (size_t)gy[q] * w + gx[q];
+        inside[q] = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+        const size_t p = inside[q] ? (size_t)y1 * w + x1 : p0;
+        const size_t pw = inside[q] ? (size_t)w : 0, p1 = inside[q] ? 1 : 0;
+        A0[q] = RA0[p0];
+        B0[q] = RB0[p0];
+        q00[q] = RA1[p]; q01[q] = RA1[p + p1]; q10[q] = RA1[p + pw]; q11[q] = RA1[p + pw + p1];
+        e00[q] = RB1[p]; e01[q] = RB1[p + p1]; e10[q] = RB1[p + pw]; e11[q] = RB1[p + pw + p1];
+    }
+    // ---- FarnebackUpdateMatrices (operation order of optflow.cpp)
+#pragma unroll
+    for (int q = 0; q < NIT; q++) {
+        float fx = fxs[q], fy = fys[q];
+        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy);
+        float a10 = (1.f - fx) * fy, a11 = fx * fy;
+        float r2 = a00 * q00[q].x + a01 * q01[q].x + a10 * q10[q].x + a11 * q11[q].x;
+        float r3 = a00 * q00[q].y + a01 * q01[q].y + a10 * q10[q].y + a11 * q11[q].y;
+        float r4 = a00 * q00[q].z + a01 * q01[q].z + a10 * q10[q].z + a11 * q11[q].z;
+        float r5 = a00 * q00[q].w + a01 * q01[q].w + a10 * q10[q].w + a11 * q11[q].w;
+        float r6 = a00 * e00[q] + a01 * e01[q] + a10 * e10[q] + a11 * e11[q];
+        r4 = (A0[q].z + r4) * 0.5f;
+        r5 = (A0[q].w + r5) * 0.5f;
+        r6 = (B0[q] + r6) * 0.25f;
+        if (!inside[q]) {
+            r2 = r3 = 0.f;
+            r4 = A0[q].z;
+            r5 = A0[q].w;
+            r6 = B0[q] * 0.5f;
+        }
+        r2 = (A0[q].x - r2) * 0.5f;
+        r3 = (A0[q].y - r3) * 0.5f;
+        r2 += r4 * dy[q] + r6 * dx[q];
+        r3 += r6 * dy[q] + r5 * dx[q];
+        const int X = gx[q], Y = gy[q];
+        if ((unsigned)(X - 5) >= (unsigned)(w - 10) || (unsigned)(Y - 5) >= (unsigned)(h - 10)) {
+            float bl = X < 5 ? (X < 2 ? 0.14f : 0.4472f) : 1.f;
+            int rx = w - X - 1;
+            float br = X >= w - 5 ? (rx < 2 ? 0.14f : 0.4472f) : 1.f;
+            float bt = Y < 5 ? (Y < 2 ? 0.14f : 0.4472f) : 1.f;
+            int ry = h - Y - 1;
+            float bb = Y >= h - 5 ? (ry < 2 ? 0.14f : 0.4472f) : 1.f;
+            float scale = bl * br * bt * bb;
+            r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+        }
+        int idx = tid + q * RC_W3_THREADS;
+        if (idx < NITEMS) {
+            int ly = idx / MW, lx = idx - ly * MW;
+            float* mp = Ms + ly * MP + lx;
+            mp[0] = r4 * r4 + r6 * r6;
+            mp[MH * MP] = (r4 + r5) * r6;
+            mp[2 * MH * MP] = r5 * r5 + r6 * r6;
+            mp[3 * MH * MP] = r4 * r2 + r6 * r3;
+            mp[4 * MH * MP] = r6 * r2 + r5 * r3;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3x3 window + solve: lane = column, RPT rows per thread
+    constexpr int RPT = TH / (RC_W3_THREADS / TW);
+    const int lx = tid % TW, r0 = (tid / TW) * RPT;
+    const int ox = tx0 + lx;
+    double g[RPT][5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const float* mc = Ms + c * MH * MP + r0 * MP + lx;
+        float col[3][RPT + 2];
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int r = 0; r < RPT + 2; r++) col[j][r] = mc[r * MP + j];
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            float v[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                if (GAUSS_) v[j] = col[j][r + 1] * a.win.k[0] + (col[j][r + 2] + col[j][r]) * a.win.k[1];
+                else v[j] = col[j][r + 1] + (col[j][r + 2] + col[j][r]);
+            }
+            if (GAUSS_) g[r][c] = v[1] * a.win.k[0] + a.win.k[1] * (v[0] + v[2]);
+            else g[r][c] = ((double)v[1] + ((double)v[2] + (double)v[0])) * a.win.box_scale;
+        }
+    }
+    if (ox < w) {
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            int oy = ty0 + r0 + r;
+            if (oy < h) *(float2*)(fout + (size_t)oy * a.fout_step + (size_t)ox * 8) = rc_solve(g[r]);
+        }
+    }
+}
+
+template <int IN_MODE, int G>
+static void launch_w3(RcIterArgs a, int pairs, hipStream_t s) {
+    a.tw = 64; a.th = 16;
+    a.tiles_x = (a.w + 63) / 64; a.tiles_y = (a.h + 15) / 16;
+    size_t lds = sizeof(float) * 5 * 18 * 67;
+    hipLaunchKernelGGL((k_flow_iter_w3<IN_MODE, G>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(RC_W3_THREADS), lds, s, a);
+}
+
+static size_t iter_lds(int tw, int th, int m, bool two_buffers) {
+    int MW = tw + 2 * m, MH = th + 2 * m, MP = MW | 1;
+    return sizeof(float) * (5 * (size_t)MH * MP + (two_buffers ? 5 * (size_t)th * MP : 0));
+}
+
+template <int TW, int TH, int M, int G>
+static void launch_iter_t(RcIterArgs a, int pairs, hipStream_t s) {
+    size_t lds = iter_lds(TW, TH, M, M > 1);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)k_flow_iter<TW, TH, M, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    a.tw = TW; a.th = TH;
+    a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
+    hipLaunchKernelGGL((k_flow_iter<TW, TH, M, G>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(RC_BLOCK), lds, s, a);
+}
+
+// Runtime tile for windows without an instantiation: best halo efficiency that fits LDS.
+static void pick_runtime_tile(int m, int& tw, int& th) {
+    static const int tiles[][2] = {{64, 16}, {32, 32}, {64, 8}, {32, 16}, {16, 16}, {16, 8}, {8, 8}};
+    double best = -1;
+    tw = 8; th = 8;
+    for (auto& t : tiles) {
+        size_t lds = iter_lds(t[0], t[1], m, true);
+        if (lds > 150 * 1024) continue;
+        double eff = (double)(t[0] * t[1]) / ((t[0] + 2 * m) * (t[1] + 2 * m));
+        if (lds > 64 * 1024) eff *= 0.6;
+        if (t[0] < 64) eff *= 0.95;
+        if (eff > best) { best = eff; tw = t[0]; th = t[1]; }
+    }
+}
+
+void rc_launch_flow_iter(const RcIterArgs& a, int pairs, hipStream_t s) {
+    const int m = a.win.m, g = a.win.gaussian ? 1 : 0;
+    if (m == 1 && a.solve) {
+        switch (a.in_mode * 2 + g) {
+            case 0: launch_w3<0, 0>(a, pairs, s); break;
+            case 1: launch_w3<0, 1>(a, pairs, s); break;
+            case 2: launch_w3<1, 0>(a, pairs, s); break;
+            case 3: launch_w3<1, 1>(a, pairs, s); break;
+            case 4: launch_w3<2, 0>(a, pairs, s); break;
+            default: launch_w3<2, 1>(a, pairs, s); break;
+        }
+        return;
+    }
+    if (m == 1) { g ? launch_iter_t<64, 16, 1, 1>(a, pairs, s) : launch_iter_t<64, 16, 1, 0>(a, pairs, s); return; }
+    if (m == 2) { g ? launch_iter_t<64, 16, 2, 1>(a, pairs, s) : launch_iter_t<64, 16, 2, 0>(a, pairs, s); return; }
+    if (m == 5) { g ? launch_iter_t<32, 32, 5, 1>(a, pairs, s) : launch_iter_t<32, 32, 5, 0>(a, pairs, s); return; }
+    if (m == 10) { g ? launch_iter_t<32, 32, 10, 1>(a, pairs, s) : launch_iter_t<32, 32, 10, 0>(a, pairs, s); return; }
+    RcIterArgs b = a;
+    pick_runtime_tile(m, b.tw, b.th);
+    b.tiles_x = (b.w + b.tw - 1) / b.tw; b.tiles_y = (b.h + b.th - 1) / b.th;
+    size_t lds = iter_lds(b.tw, b.th, m, true);
+    static size_t attr = 0;
+    if (lds > attr) {
+        (void)hipFuncSetAttribute((const void*)k_flow_iter<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    hipLaunchKernelGGL((k_flow_iter<0, 0, 0, 0>), dim3(b.tiles_x * b.tiles_y, pairs, 1), dim3(RC_BLOCK), lds, s, b);
+}

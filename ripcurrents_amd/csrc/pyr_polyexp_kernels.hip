@@ -1,0 +1,505 @@
+// pyr_polyexp_kernels.hip -- gfx950 kernels for the image side of dense Farneback flow.
+//
+// Replaces the arithmetic behind cv::calcOpticalFlowFarneback as the reference calls it
+// (RipCurrents_main/ripcurrents.cpp:215; main.cpp:264,609,742,961,1119,1481).  Stages
+// follow SURVEY.md section 8(a):
+//   k_pyr_level   A1  convertTo(32F) + GaussianBlur(full res, REFLECT_101) + resize(LINEAR)
+//   k_polyexp     A2  FarnebackPolyExp            -> R = (y, x, yy, xx | xy) planes
+//   (flow_iter_kernels.hip holds A3-A6)
+// Data layout in HBM (all fp32):
+//   I_k   [slot][h][w]            float
+//   RA_k  [slot][h][w]            float4 (y, x, yy, xx)  -- one 16-B load per pixel/texel
+//   RB_k  [slot][h][w]            float  (xy)
+//   flow  [pair][h][w]            float2 (x, y)  == CV_32FC2
+// Compiled with -ffp-contract=off; fused multiply-adds are written explicitly (RC_FMA)
+// in the convolution loops and nowhere else, so the gather / matrix / resize arithmetic
+// rounds operation by operation like the scalar C++ it has to match.
+
+#include "rc_device.h"
+
+// ===================================================================== A1 pyramid
+// One block = tw x th output pixels of scale k >= 1 (scale 0 is fused into k_polyexp).
+// The 8-bit source region the tile needs (blur radius + resize footprint) is staged in
+// LDS, the horizontal blur is evaluated only at the two source columns each output column
+// samples, then each thread does the vertical blur at its 2x2 sample points and the
+// bilinear resize.  The resize.cpp coordinate tables (xofs/alpha, yofs/beta) are built
+// once per block in LDS; loops are row-per-wave so no index needs a division.
+__global__ __launch_bounds__(RC_BLOCK) void k_pyr_level(RcPyrArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* reg = smem;                                    // [reg_hmax][reg_wp] u8
+    float* rp = (float*)(smem + (size_t)a.reg_hmax * a.reg_wp);   // [reg_hmax][2*tw]
+    int* xs = (int*)(rp + (size_t)a.reg_hmax * 2 * a.tw);         // [2*tw] source column per (dx, tap)
+    float* xa = (float*)(xs + 2 * a.tw);                          // [tw]  alpha
+    int* ys = (int*)(xa + a.tw);                                  // [2*th] clamped rows sy0, sy1
+    float* ya = (float*)(ys + 2 * a.th);                          // [th]  beta
+    float* ks = ya + a.th;                                        // [ksize] blur taps
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int z = blockIdx.z;
+    const int tx0 = blockIdx.x * a.tw, ty0 = blockIdx.y * a.th;
+    const int r = a.ksize >> 1;
+    const int W0 = a.W0, H0 = a.H0;
+
+    if (tid < a.tw) {
+        float ax;
+        int sx = rc_src_x(min(tx0 + tid, a.w - 1), a.scale_x, W0, ax);
+        xs[2 * tid] = sx;
+        xs[2 * tid + 1] = min(sx + 1, W0 - 1);
+        xa[tid] = ax;
+    } else if (tid >= 64 && tid < 128) {
+        for (int k = tid - 64; k < a.ksize; k += 64) ks[k] = a.kern[k];
+    } else if (tid >= 128 && tid < 128 + a.th) {
+        int i = tid - 128;
+        float ay;
+        int sy = rc_src_y(min(ty0 + i, a.h - 1), a.scale_y, ay);
+        ys[2 * i] = rc_clampi(sy, 0, H0 - 1);
+        ys[2 * i + 1] = rc_clampi(sy + 1, 0, H0 - 1);
+        ya[i] = ay;
+    }
+    __syncthreads();
+    const int nx = min(a.tw, a.w - tx0), ny = min(a.th, a.h - ty0);
+    const int reg_x0 = xs[0] - r, reg_x1 = xs[2 * nx - 1] + r;
+    const int reg_y0 = ys[0] - r, reg_y1 = ys[2 * ny - 1] + r;
+    const int reg_w = reg_x1 - reg_x0 + 1, reg_h = reg_y1 - reg_y0 + 1;
+
+    // region load, 16 rows in flight per thread (a dependent load->LDS-store loop would
+    // serialise one HBM round trip per element)
+    const uint8_t* src = a.src + (size_t)z * a.src_frame_stride;
+    for (int j = lane; j < reg_w; j += 64) {
+        const int sx = rc_reflect101(reg_x0 + j, W0);
+        for (int ib = wv; ib < reg_h; ib += 16 * (RC_BLOCK / 64)) {
+            unsigned char v[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                int i = ib + q * (RC_BLOCK / 64);
+                v[q] = i < reg_h ? src[(size_t)rc_reflect101(reg_y0 + i, H0) * a.src_step + sx] : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                int i = ib + q * (RC_BLOCK / 64);
+                if (i < reg_h) reg[i * a.reg_wp + j] = v[q];
+            }
+        }
+    }
+    __syncthreads();
+
+    // horizontal blur (RowFilter order of smooth.cpp; SymmRowSmallFilter for ksize<=5)
+    const int tw2 = 2 * a.tw;
+    const float* kern = ks;
+    for (int i = wv; i < reg_h; i += RC_BLOCK / 64) {
+        for (int j = lane; j < tw2; j += 64) {
+            const unsigned char* S = reg + i * a.reg_wp + (xs[j] - reg_x0);
+            float s0;
+            if (a.ksize == 3) {
+                s0 = (float)S[0] * kern[1] + ((float)S[-1] + (float)S[1]) * kern[2];
+            } else if (a.ksize == 5) {
+                s0 = (float)S[0] * kern[2] + ((float)S[-1] + (float)S[1]) * kern[3] +
+                     ((float)S[-2] + (float)S[2]) * kern[4];
+            } else {
+                s0 = kern[0] * (float)S[-r];
+                for (int k = 1; k < a.ksize; k++) s0 += kern[k] * (float)S[k - r];
+            }
+            rp[i * tw2 + j] = s0;
+        }
+    }
+    __syncthreads();
+
+    const int slot = (a.dslot0 + z) % a.nslots;
+    float* dst = a.dst + (size_t)slot * a.dst_slot_stride;
+    for (int ly = wv; ly < ny; ly += RC_BLOCK / 64) {
+        const int i0 = ys[2 * ly] - reg_y0, i1 = ys[2 * ly + 1] - reg_y0;
+        const float ay = ya[ly];
+        for (int lx = lane; lx < nx; lx += 64) {
+            const float* c0 = rp + 2 * lx;
+            // vertical blur (SymmColumnFilter order) at the four sample points
+            float b00 = kern[r] * c0[i0 * tw2], b01 = kern[r] * c0[i0 * tw2 + 1];
+            float b10 = kern[r] * c0[i1 * tw2], b11 = kern[r] * c0[i1 * tw2 + 1];
+            for (int k = 1; k <= r; k++) {
+                float kk = kern[r + k];
+                b00 += kk * (c0[(i0 + k) * tw2] + c0[(i0 - k) * tw2]);
+                b01 += kk * (c0[(i0 + k) * tw2 + 1] + c0[(i0 - k) * tw2 + 1]);
+                b10 += kk * (c0[(i1 + k) * tw2] + c0[(i1 - k) * tw2]);
+                b11 += kk * (c0[(i1 + k) * tw2 + 1] + c0[(i1 - k) * tw2 + 1]);
+            }
+            const float ax = xa[lx];
+            float a0 = 1.f - ax, a1 = ax, w0 = 1.f - ay, w1 = ay;
+            float r0 = b00 * a0 + b01 * a1;
+            float r1 = b10 * a0 + b11 * a1;
+            dst[(size_t)(ty0 + ly) * a.w + tx0 + lx] = r0 * w0 + r1 * w1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Direct form for small blur radii (scales 1 and 2 at pyr_scale 0.5: 3 and 9 taps): one
+// thread per output pixel, no LDS and no barrier.  Each needed source row arrives as a few
+// aligned dwords (neighbouring threads share them in L1) and is byte-aligned with
+// v_alignbyte; pixels whose footprint touches the image border take the per-byte
+// REFLECT_101 path.  Same operation order as the tiled kernel (bit-identical results).
+template <int R>
+__device__ __forceinline__ float rc_rowpass(const float* b, const float* k) {
+    if (R == 1) return b[1] * k[1] + (b[0] + b[2]) * k[2];
+    if (R == 2) return b[2] * k[2] + (b[1] + b[3]) * k[3] + (b[0] + b[4]) * k[4];
+    float s = k[0] * b[0];
+#pragma unroll
+    for (int j = 1; j < 2 * R + 1; j++) s += k[j] * b[j];
+    return s;
+}
+
+template <int R>
+__global__ __launch_bounds__(RC_BLOCK) void k_pyr_direct(RcPyrArgs a) {
+    constexpr int KS = 2 * R + 1, NB = 2 * R + 2, NDW = (2 * R + 8) / 4, NROW = 2 * R + 2;
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int z = blockIdx.z;
+    if (dx >= a.w || dy >= a.h) return;
+    const int W0 = a.W0, H0 = a.H0;
+    float k[KS];
+#pragma unroll
+    for (int j = 0; j < KS; j++) k[j] = a.kern[j];
+    float ax, ay;
+    const int sx = rc_src_x(dx, a.scale_x, W0, ax);
+    const int sx1 = min(sx + 1, W0 - 1);
+    const int sy = rc_src_y(dy, a.scale_y, ay);
+    const int y0 = rc_clampi(sy, 0, H0 - 1), y1 = rc_clampi(sy + 1, 0, H0 - 1);
+    const uint8_t* src = a.src + (size_t)z * a.src_frame_stride;
+    const int xs = sx - R, xa = xs & ~3, off = xs & 3;
+    const bool aligned = ((((size_t)a.src) | a.src_step | a.src_frame_stride) & 3) == 0;
+    const bool fast = aligned && sx1 == sx + 1 && y1 == y0 + 1 && xs >= 0 && xa + 4 * NDW <= W0 &&
+                      sx1 + R <= W0 - 1 && y0 - R >= 0 && y1 + R <= H0 - 1;
+    float b00, b01, b10, b11;
+    if (fast) {
+        unsigned int dw[NROW][NDW];
+#pragma unroll
+        for (int rr = 0; rr < NROW; rr++) {
+            const unsigned int* row = (const unsigned int*)(src + (size_t)(y0 - R + rr) * a.src_step + xa);
+#pragma unroll
+            for (int j = 0; j < NDW; j++) dw[rr][j] = row[j];
+        }
+        float rp0[NROW], rp1[NROW];
+#pragma unroll
+        for (int rr = 0; rr < NROW; rr++) {
+            float b[NB];
+#pragma unroll
+            for (int j = 0; j < (NB + 3) / 4; j++) {
+                unsigned int sd = j + 1 < NDW ? __builtin_amdgcn_alignbyte(dw[rr][j + 1], dw[rr][j], off)
+                                              : (dw[rr][j] >> (8 * off));
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (4 * j + t < NB) b[4 * j + t] = (float)((sd >> (8 * t)) & 255u);
+            }
+            rp0[rr] = rc_rowpass<R>(b, k);
+            rp1[rr] = rc_rowpass<R>(b + 1, k);
+        }
+        b00 = k[R] * rp0[R]; b01 = k[R] * rp1[R];
+        b10 = k[R] * rp0[R + 1]; b11 = k[R] * rp1[R + 1];
+#pragma unroll
+        for (int j = 1; j <= R; j++) {
+            b00 += k[R + j] * (rp0[R + j] + rp0[R - j]);
+            b01 += k[R + j] * (rp1[R + j] + rp1[R - j]);
+            b10 += k[R + j] * (rp0[R + 1 + j] + rp0[R + 1 - j]);
+            b11 += k[R + j] * (rp1[R + 1 + j] + rp1[R + 1 - j]);
+        }
+    } else {
+        float bv[4];
+#pragma unroll
+        for (int pt = 0; pt < 4; pt++) {
+            const int cx = (pt & 1) ? sx1 : sx, cy = (pt & 2) ? y1 : y0;
+            float rp[KS];
+            for (int rr = 0; rr < KS; rr++) {
+                const uint8_t* row = src + (size_t)rc_reflect101(cy - R + rr, H0) * a.src_step;
+                float b[KS];
+#pragma unroll
+                for (int j = 0; j < KS; j++) b[j] = (float)row[rc_reflect101(cx - R + j, W0)];
+                rp[rr] = rc_rowpass<R>(b, k);
+            }
+            float v = k[R] * rp[R];
+#pragma unroll
+            for (int j = 1; j <= R; j++) v += k[R + j] * (rp[R + j] + rp[R - j]);
+            bv[pt] = v;
+        }
+        b00 = bv[0]; b01 = bv[1]; b10 = bv[2]; b11 = bv[3];
+    }
+    float a0 = 1.f - ax, a1 = ax, w0 = 1.f - ay, w1 = ay;
+    float r0 = b00 * a0 + b01 * a1;
+    float r1 = b10 * a0 + b11 * a1;
+    const int slot = (a.dslot0 + z) % a.nslots;
+    a.dst[(size_t)slot * a.dst_slot_stride + (size_t)dy * a.w + dx] = r0 * w0 + r1 * w1;
+}
+
+void rc_launch_pyr(const RcPyrArgs& a, int frames, size_t lds, hipStream_t s) {
+    if (a.ksize == 3 || a.ksize == 9) {
+        dim3 grid((a.w + 63) / 64, (a.h + 3) / 4, frames);
+        if (a.ksize == 3) hipLaunchKernelGGL(k_pyr_direct<1>, grid, dim3(RC_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL(k_pyr_direct<4>, grid, dim3(RC_BLOCK), 0, s, a);
+        return;
+    }
+    dim3 grid((a.w + a.tw - 1) / a.tw, (a.h + a.th - 1) / a.th, frames);
+    hipLaunchKernelGGL(k_pyr_level, grid, dim3(RC_BLOCK), lds, s, a);
+}
+
+// ===================================================================== A2 polyexp
+// 64x32 output tile per 512-thread block.  Separable: horizontal pass first (three sums
+// per pixel: g, x*g, x*x*g), staged through LDS, vertical pass last so that every lane of
+// a wave owns one column and all LDS reads and the 16-B global stores are conflict-free
+// and coalesced.  Each thread of the vertical pass produces 4 rows from a register
+// window.  A per-tile constant is subtracted before the sums and its exact contribution
+// (pk.kdc) is added back in the double-precision epilogue: the yy/xx coefficients are
+// differences of O(100) sums, and this keeps them at fp32's best.
+// U8 = 1 fuses scale 0 of the pyramid (A1 at scale 1: convertTo + 3x3 [1/4,1/2,1/4] blur,
+// REFLECT_101; the resize is the identity) into the tile load, so the full-resolution
+// float image never exists in HBM.
+#define RC_POLY_BLOCK 512
+template <int R, int U8>
+__global__ __launch_bounds__(RC_POLY_BLOCK) void k_polyexp(RcPolyArgs a) {
+    constexpr int TW = 64, TH = 32, RP = (R + 3) & ~3;
+    constexpr int INW = TW + 2 * RP, INH = TH + 2 * R;
+    constexpr int NV = 4 + 2 * RP;
+    constexpr int UBW = (INW + 2 + 3) & ~3, UBH = INH + 2;
+    extern __shared__ __align__(16) float smf[];
+    float* tin = smf;                // [INH][INW]
+    float* hs = smf + INH * INW;     // [3][INH][TW]
+    const int tid = threadIdx.x;
+    const int z = blockIdx.z;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const int w = a.w, h = a.h;
+    const int slot = (a.slot0 + z) % a.nslots;
+    float dc;
+
+    if constexpr (U8) {
+        unsigned char* ub = (unsigned char*)(hs + 3 * INH * TW);   // [UBH][UBW]
+        const uint8_t* src = a.src8 + (size_t)z * a.src8_frame_stride;
+        const int xlo = rc_clampi(tx0 - RP, 0, w - 1) - 1, ylo = rc_clampi(ty0 - R, 0, h - 1) - 1;
+        dc = (float)src[(size_t)min(ty0 + TH / 2, h - 1) * a.src8_step + min(tx0 + TW / 2, w - 1)];
+        {
+            constexpr int NLD = (UBH * UBW + RC_POLY_BLOCK - 1) / RC_POLY_BLOCK;
+            unsigned char v[NLD];
+#pragma unroll
+            for (int q = 0; q < NLD; q++) {     // all loads in flight before the first LDS store
+                int idx = tid + q * RC_POLY_BLOCK;
+                int i = idx / UBW, j = idx - i * UBW;
+                int sy = rc_reflect101(min(ylo + i, h), h), sx = rc_reflect101(min(xlo + j, w), w);
+                v[q] = idx < UBH * UBW ? src[(size_t)sy * a.src8_step + sx] : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < NLD; q++) {
+                int idx = tid + q * RC_POLY_BLOCK;
+                if (idx < UBH * UBW) ub[idx] = v[q];
+            }
+        }
+        __syncthreads();
+        if (tx0 - RP >= 0 && tx0 + TW + RP <= w && ty0 - R >= 0 && ty0 + TH + R <= h) {
+            // interior tile: no clamping, tin(i, j) sits at ub(i + 1, j + 1); one thread blurs
+            // four consecutive pixels from three rows of two aligned dwords each
+            for (int idx = tid; idx < INH * (INW / 4); idx += RC_POLY_BLOCK) {
+                int i = idx / (INW / 4), j4 = idx - i * (INW / 4);
+                const unsigned int* U = (const unsigned int*)(ub + i * UBW + 4 * j4);
+                float rr[3][4];
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    unsigned int lo = U[t * (UBW / 4)], hi = U[t * (UBW / 4) + 1];
+                    float b0 = (float)(lo & 255u), b1 = (float)((lo >> 8) & 255u), b2 = (float)((lo >> 16) & 255u),
+                          b3 = (float)(lo >> 24), b4 = (float)(hi & 255u), b5 = (float)((hi >> 8) & 255u);
+                    rr[t][0] = b1 * 0.5f + (b0 + b2) * 0.25f;
+                    rr[t][1] = b2 * 0.5f + (b1 + b3) * 0.25f;
+                    rr[t][2] = b3 * 0.5f + (b2 + b4) * 0.25f;
+                    rr[t][3] = b4 * 0.5f + (b3 + b5) * 0.25f;
+                }
+                float4 o;
+                o.x = (0.5f * rr[1][0] + 0.25f * (rr[2][0] + rr[0][0])) - dc;
+                o.y = (0.5f * rr[1][1] + 0.25f * (rr[2][1] + rr[0][1])) - dc;
+                o.z = (0.5f * rr[1][2] + 0.25f * (rr[2][2] + rr[0][2])) - dc;
+                o.w = (0.5f * rr[1][3] + 0.25f * (rr[2][3] + rr[0][3])) - dc;
+                *(float4*)(tin + i * INW + 4 * j4) = o;
+            }
+        } else {
+            for (int idx = tid; idx < INH * INW; idx += RC_POLY_BLOCK) {
+                int i = idx / INW, j = idx - i * INW;
+                int gy = rc_clampi(ty0 - R + i, 0, h - 1), gx = rc_clampi(tx0 - RP + j, 0, w - 1);
+                const unsigned char* S = ub + (gy - ylo) * UBW + (gx - xlo);
+                // smooth.cpp: row filter then column filter, ksize 3, kernel (1/4, 1/2, 1/4)
+                float r0 = (float)S[-UBW] * 0.5f + ((float)S[-UBW - 1] + (float)S[-UBW + 1]) * 0.25f;
+                float r1 = (float)S[0] * 0.5f + ((float)S[-1] + (float)S[1]) * 0.25f;
+                float r2 = (float)S[UBW] * 0.5f + ((float)S[UBW - 1] + (float)S[UBW + 1]) * 0.25f;
+                float v = 0.5f * r1 + 0.25f * (r2 + r0);
+                tin[idx] = v - dc;
+            }
+        }
+    } else {
+        const float* I = a.I + (size_t)slot * a.I_slot_stride;
+        dc = I[(size_t)min(ty0 + TH / 2, h - 1) * w + min(tx0 + TW / 2, w - 1)];
+        constexpr int NLD = (INH * INW + RC_POLY_BLOCK - 1) / RC_POLY_BLOCK;
+        float v[NLD];
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            int idx = tid + q * RC_POLY_BLOCK;
+            int i = idx / INW, j = idx - i * INW;
+            int gy = rc_clampi(ty0 - R + i, 0, h - 1), gx = rc_clampi(tx0 - RP + j, 0, w - 1);
+            v[q] = idx < INH * INW ? I[(size_t)gy * w + gx] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            int idx = tid + q * RC_POLY_BLOCK;
+            if (idx < INH * INW) tin[idx] = v[q] - dc;
+        }
+    }
+    __syncthreads();
+
+    // horizontal pass: item = (row i, group of 4 pixels)
+    for (int idx = tid; idx < INH * (TW / 4); idx += RC_POLY_BLOCK) {
+        int i = idx / (TW / 4), g4 = idx - i * (TW / 4);
+        float v[NV];
+        const float4* p4 = (const float4*)(tin + i * INW + 4 * g4);
+#pragma unroll
+        for (int q = 0; q < NV / 4; q++) {
+            float4 t = p4[q];
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+        float h0[4], h1[4], h2[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int c = RP + p;
+            float s0 = v[c] * a.pk.g[0], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 1; k <= R; k++) {
+                float sm = v[c + k] + v[c - k], df = v[c + k] - v[c - k];
+                s0 = RC_FMA(sm, a.pk.g[k], s0);
+                s1 = RC_FMA(df, a.pk.xg[k], s1);
+                s2 = RC_FMA(sm, a.pk.xxg[k], s2);
+            }
+            h0[p] = s0; h1[p] = s1; h2[p] = s2;
+        }
+        float4* o = (float4*)(hs + i * TW + 4 * g4);
+        o[0] = make_float4(h0[0], h0[1], h0[2], h0[3]);
+        o[INH * TW / 4] = make_float4(h1[0], h1[1], h1[2], h1[3]);
+        o[2 * INH * TW / 4] = make_float4(h2[0], h2[1], h2[2], h2[3]);
+    }
+    __syncthreads();
+
+    // vertical pass: lane = column, NR output rows per thread
+    constexpr int NR = TH / (RC_POLY_BLOCK / 64);
+    const int x = tid & 63, o0 = (tid >> 6) * NR;
+    constexpr int NW = NR + 2 * R;
+    float b1[NR], b2[NR], b3[NR], b4[NR], b5[NR], b6[NR];
+    {
+        float c[NW];
+#pragma unroll
+        for (int q = 0; q < NW; q++) c[q] = hs[(o0 + q) * TW + x];
+#pragma unroll
+        for (int o = 0; o < NR; o++) {
+            float s1 = c[o + R] * a.pk.g[0], s3 = 0.f, s5 = 0.f;
+#pragma unroll
+            for (int k = 1; k <= R; k++) {
+                float sm = c[o + R + k] + c[o + R - k], df = c[o + R + k] - c[o + R - k];
+                s1 = RC_FMA(sm, a.pk.g[k], s1);
+                s3 = RC_FMA(df, a.pk.xg[k], s3);
+                s5 = RC_FMA(sm, a.pk.xxg[k], s5);
+            }
+            b1[o] = s1; b3[o] = s3; b5[o] = s5;
+        }
+    }
+    {
+        float c[NW];
+#pragma unroll
+        for (int q = 0; q < NW; q++) c[q] = hs[INH * TW + (o0 + q) * TW + x];
+#pragma unroll
+        for (int o = 0; o < NR; o++) {
+            float s2 = c[o + R] * a.pk.g[0], s6 = 0.f;
+#pragma unroll
+            for (int k = 1; k <= R; k++) {
+                s2 = RC_FMA(c[o + R + k] + c[o + R - k], a.pk.g[k], s2);
+                s6 = RC_FMA(c[o + R + k] - c[o + R - k], a.pk.xg[k], s6);
+            }
+            b2[o] = s2; b6[o] = s6;
+        }
+    }
+    {
+        float c[NW];
+#pragma unroll
+        for (int q = 0; q < NW; q++) c[q] = hs[2 * INH * TW + (o0 + q) * TW + x];
+#pragma unroll
+        for (int o = 0; o < NR; o++) {
+            float s4 = c[o + R] * a.pk.g[0];
+#pragma unroll
+            for (int k = 1; k <= R; k++) s4 = RC_FMA(c[o + R + k] + c[o + R - k], a.pk.g[k], s4);
+            b4[o] = s4;
+        }
+    }
+    const int gx = tx0 + x;
+    if (gx < w) {
+        float4* RA = a.RA + (size_t)slot * a.R_slot_stride;
+        float* RB = a.RB + (size_t)slot * a.R_slot_stride;
+        const double dck = (double)dc * a.pk.kdc;
+        const float ig11f = (float)a.pk.ig11, ig55f = (float)a.pk.ig55;
+#pragma unroll
+        for (int o = 0; o < NR; o++) {
+            int gy = ty0 + o0 + o;
+            if (gy < h) {
+                float4 ra;
+                ra.x = b3[o] * ig11f;
+                ra.y = b2[o] * ig11f;
+                ra.z = (float)((double)b1[o] * a.pk.ig03 + (double)b5[o] * a.pk.ig33 + dck);
+                ra.w = (float)((double)b1[o] * a.pk.ig03 + (double)b4[o] * a.pk.ig33 + dck);
+                size_t p = (size_t)gy * w + gx;
+                RA[p] = ra;
+                RB[p] = b6[o] * ig55f;
+            }
+        }
+    }
+}
+
+template <int R, int U8>
+static void launch_polyexp_t(const RcPolyArgs& a, int frames, hipStream_t s) {
+    constexpr int RP = (R + 3) & ~3;
+    constexpr int INW = 64 + 2 * RP, INH = 32 + 2 * R;
+    size_t lds = sizeof(float) * ((size_t)INH * INW + 3 * (size_t)INH * 64);
+    if (U8) lds += (size_t)(INH + 2) * ((INW + 2 + 3) & ~3);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_polyexp<R, U8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((a.w + 63) / 64, (a.h + 31) / 32, frames);
+    hipLaunchKernelGGL((k_polyexp<R, U8>), grid, dim3(RC_POLY_BLOCK), lds, s, a);
+}
+
+template <int U8>
+static void launch_polyexp_u(const RcPolyArgs& a, int frames, hipStream_t s) {
+    int n = a.pk.n_eff;
+    if (n <= 3) launch_polyexp_t<3, U8>(a, frames, s);
+    else if (n <= 5) launch_polyexp_t<5, U8>(a, frames, s);
+    else if (n <= 7) launch_polyexp_t<7, U8>(a, frames, s);
+    else if (n <= 8) launch_polyexp_t<8, U8>(a, frames, s);
+    else if (n <= 9) launch_polyexp_t<9, U8>(a, frames, s);
+    else if (n <= 12) launch_polyexp_t<12, U8>(a, frames, s);
+    else if (n <= 16) launch_polyexp_t<16, U8>(a, frames, s);
+    else if (n <= 24) launch_polyexp_t<24, U8>(a, frames, s);
+    else launch_polyexp_t<32, U8>(a, frames, s);
+}
+
+void rc_launch_polyexp(const RcPolyArgs& a, int frames, hipStream_t s) {
+    if (a.src8) launch_polyexp_u<1>(a, frames, s);
+    else launch_polyexp_u<0>(a, frames, s);
+}
+
+// ===================================================================== test helpers
+__global__ void k_pack_R5(const float* R5, float4* RA, float* RB, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        RA[i] = make_float4(R5[5 * i], R5[5 * i + 1], R5[5 * i + 2], R5[5 * i + 3]);
+        RB[i] = R5[5 * i + 4];
+    }
+}
+__global__ void k_unpack_R5(const float4* RA, const float* RB, float* R5, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float4 v = RA[i];
+        R5[5 * i] = v.x; R5[5 * i + 1] = v.y; R5[5 * i + 2] = v.z; R5[5 * i + 3] = v.w;
+        R5[5 * i + 4] = RB[i];
+    }
+}
+void rc_launch_pack_R5(const float* R5, float4* RA, float* RB, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_R5, dim3((n + 255) / 256), dim3(256), 0, s, R5, RA, RB, n);
+}
+void rc_launch_unpack_R5(const float4* RA, const float* RB, float* R5, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_unpack_R5, dim3((n + 255) / 256), dim3(256), 0, s, RA, RB, R5, n);
+}

@@ -60,8 +60,10 @@ struct RcPyrArgs {
 };
 
 struct RcPolyArgs {
-    const float* I;           // I_k slot base
+    const float* I;           // I_k slot base (scales >= 1, and the stage entry point)
     size_t I_slot_stride;
+    const uint8_t* src8;      // scale 0: the 8-bit frames themselves (pyramid fused); else NULL
+    size_t src8_step, src8_frame_stride;
     float4* RA;               // (y, x, yy, xx) coefficients
     float* RB;                // xy coefficient
     size_t R_slot_stride;     // elements per slot (pixels)
@@ -87,7 +89,7 @@ struct RcIterArgs {
     char* fout;
     size_t fout_step;         // bytes per row
     size_t fout_pair_stride;  // bytes per pair
-    int tw, th;               // tile
+    int tw, th;               // tile (filled by the launcher)
     int tiles_x, tiles_y;
     int solve;                // 0: write flow_in (iterations == 0), 1: normal
     RcWindow win;
@@ -96,7 +98,6 @@ struct RcIterArgs {
 void rc_launch_pyr(const RcPyrArgs& a, int frames, size_t lds, hipStream_t s);
 void rc_launch_polyexp(const RcPolyArgs& a, int frames, hipStream_t s);
 void rc_launch_flow_iter(const RcIterArgs& a, int pairs, hipStream_t s);
-size_t rc_flow_iter_lds(int tw, int th, int m);
 
 // interleave helpers for the stage-level test entry points
 void rc_launch_pack_R5(const float* R5, float4* RA, float* RB, int n, hipStream_t s);

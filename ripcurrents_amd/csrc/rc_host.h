@@ -20,7 +20,6 @@ struct RcPlan {
     size_t kern_off[RC_MAX_LEVELS];
     RcPolyK pk;
     RcWindow win;
-    int iter_tw = 64, iter_th = 16;
     int nslots = 0, chunk = 0;
     int exact_taps = 0;
 };
@@ -29,6 +28,7 @@ struct RcPlan {
 struct RcAnalysis {
     int w = 0, h = 0;
     RcBuf hist;        // RC_HIST_WORDS int32
+    RcBuf hist_part;   // partial hist2d tables of the histogram kernel
     RcBuf thr;         // UPPER | UPPER2d[36] | prop[36] floats (+1 pad)
     RcBuf acc;         // h*w float accumulator (.x channel of the reference's 32FC3)
     RcBuf pt;          // h*w float2 streamlines_mat

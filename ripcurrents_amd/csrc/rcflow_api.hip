@@ -175,7 +175,7 @@ static void slot_free(RcSlot& s) {
     }
     rc_buf_free(s.stage_u8); rc_buf_free(s.stage_flow);
     for (auto& b : s.stage_f32) rc_buf_free(b);
-    rc_buf_free(s.an.hist); rc_buf_free(s.an.thr); rc_buf_free(s.an.acc);
+    rc_buf_free(s.an.hist); rc_buf_free(s.an.hist_part); rc_buf_free(s.an.thr); rc_buf_free(s.an.acc);
     rc_buf_free(s.an.pt); rc_buf_free(s.an.dist); rc_buf_free(s.an.scratch);
     if (s.own) (void)hipStreamDestroy(s.own);
     s.own = s.cur = nullptr;
@@ -204,7 +204,14 @@ extern "C" int rcflow_sync(rc_ctx* ctx, int stream) {
 extern "C" int rcflow_set_hip_stream(rc_ctx* ctx, int stream, void* hip_stream) {
     RcSlot* s = rc_slot(ctx, stream);
     if (!s) return RC_EINVAL;
-    s->cur = hip_stream ? (hipStream_t)hip_stream : s->own;
+    s->cur = (hipStream_t)hip_stream;
+    return RC_OK;
+}
+
+extern "C" int rcflow_use_own_stream(rc_ctx* ctx, int stream) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    s->cur = s->own;
     return RC_OK;
 }
 
@@ -347,7 +354,7 @@ static int host_prepare_poly(int n, double sigma, int exact_taps, RcPolyK& pk) {
         }
         if (n_thr < 1) n_thr = 1;
     }
-    static const int inst[] = {3, 5, 7, 9, 12, 16, 24, 32};
+    static const int inst[] = {3, 5, 7, 8, 9, 12, 16, 24, 32};
     int R = 32;
     for (int v : inst)
         if (v >= n_thr) { R = v; break; }
@@ -385,7 +392,8 @@ static void host_window(int winsize, int flags, RcWindow& win) {
 }
 
 static void pick_pyr_tile(RcLevel& L, int W0, int H0) {
-    static const int tiles[][2] = {{64, 4}, {32, 8}, {16, 8}, {16, 4}, {8, 4}, {4, 4}, {2, 2}, {1, 1}};
+    // tw <= 128 and th <= 128 (the coordinate tables are filled by threads 0..127 / 128..255)
+    static const int tiles[][2] = {{64, 16}, {64, 8}, {64, 4}, {32, 8}, {16, 8}, {16, 4}, {8, 4}, {4, 4}, {2, 2}, {1, 1}};
     int r = L.ksize / 2;
     for (auto& t : tiles) {
         int tw = t[0], th = t[1];
@@ -394,25 +402,11 @@ static void pick_pyr_tile(RcLevel& L, int W0, int H0) {
         if (rw > W0 + 2 * r + 2) rw = W0 + 2 * r + 2;
         if (rh > H0 + 2 * r + 2) rh = H0 + 2 * r + 2;
         int rwp = (rw + 15) & ~15;
-        size_t lds = (size_t)rh * rwp + sizeof(float) * (size_t)rh * 2 * tw;
-        if (lds <= 60 * 1024 || tw == 1) {
+        size_t lds = (size_t)rh * rwp + sizeof(float) * ((size_t)rh * 2 * tw + 3 * tw + 3 * th + L.ksize);
+        if (lds <= 40 * 1024 || tw == 1) {
             L.pyr_tw = tw; L.pyr_th = th; L.pyr_reg_w = rwp; L.pyr_reg_h = rh; L.pyr_lds = lds;
             return;
         }
-    }
-}
-
-static void pick_iter_tile(RcPlan& pl) {
-    static const int tiles[][2] = {{64, 16}, {32, 32}, {64, 8}, {32, 16}, {16, 16}, {16, 8}, {8, 8}};
-    int m = pl.win.m;
-    double best = -1;
-    for (auto& t : tiles) {
-        size_t lds = rc_flow_iter_lds(t[0], t[1], m);
-        if (lds > 150 * 1024) continue;
-        double eff = (double)(t[0] * t[1]) / ((t[0] + 2 * m) * (t[1] + 2 * m));
-        if (lds > 64 * 1024) eff *= 0.6;      // one block per CU only
-        if (t[0] < 64) eff *= 0.95;           // 16-B coalescing prefers 64-wide rows
-        if (eff > best) { best = eff; pl.iter_tw = t[0]; pl.iter_th = t[1]; }
     }
 }
 
@@ -458,7 +452,6 @@ static int ensure_plan(rc_ctx* ctx, RcSlot& s, int w, int h, const rc_farneback_
     int rc = host_prepare_poly(p->poly_n, p->poly_sigma, ctx->exact_taps, pl.pk);
     if (rc) { rc_set_error("polynomial-expansion moment matrix is not positive definite"); return rc; }
     host_window(p->winsize, p->flags, pl.win);
-    pick_iter_tile(pl);
 
     std::vector<float> kh(kern_total, 0.f);
     for (int k = 0; k <= L; k++) host_gaussian_kernel(pl.lv[k].ksize, pl.lv[k].sigma > 0 ? pl.lv[k].sigma : 0., kh.data() + pl.kern_off[k]);
@@ -466,7 +459,7 @@ static int ensure_plan(rc_ctx* ctx, RcSlot& s, int w, int h, const rc_farneback_
     RC_HIP(hipMemcpy(s.kern.p, kh.data(), kern_total * sizeof(float), hipMemcpyHostToDevice));
     for (int k = 0; k <= L; k++) {
         size_t n = (size_t)pl.lv[k].w * pl.lv[k].h;
-        if ((rc = rc_buf_ensure(s.I[k], n * pl.nslots * sizeof(float)))) return rc;
+        if (k > 0 && (rc = rc_buf_ensure(s.I[k], n * pl.nslots * sizeof(float)))) return rc;
         if ((rc = rc_buf_ensure(s.RA[k], n * pl.nslots * sizeof(float4)))) return rc;
         if ((rc = rc_buf_ensure(s.RB[k], n * pl.nslots * sizeof(float)))) return rc;
         if ((rc = rc_buf_ensure(s.FA[k], n * chunk * sizeof(float2)))) return rc;
@@ -485,6 +478,17 @@ static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t fr
     for (int k = 0; k < pl.nlev; k++) {
         const RcLevel& L = pl.lv[k];
         size_t n = (size_t)L.w * L.h;
+        RcPolyArgs qa;
+        memset(&qa, 0, sizeof(qa));
+        qa.RA = (float4*)s.RA[k].p; qa.RB = (float*)s.RB[k].p; qa.R_slot_stride = n;
+        qa.slot0 = dslot0; qa.nslots = pl.nslots; qa.w = L.w; qa.h = L.h; qa.pk = pl.pk;
+        if (k == 0) {
+            // scale 0: pyramid (3x3 blur, identity resize) fused into the expansion
+            qa.src8 = d_src; qa.src8_step = step; qa.src8_frame_stride = frame_stride;
+            RcProfScope ps(ctx, s.cur, RC_K_POLY, k, (double)count * 21. * n);
+            rc_launch_polyexp(qa, count, s.cur);
+            continue;
+        }
         RcPyrArgs pa;
         pa.src = d_src; pa.src_step = step; pa.src_frame_stride = frame_stride;
         pa.W0 = pl.w; pa.H0 = pl.h;
@@ -497,10 +501,7 @@ static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t fr
             RcProfScope ps(ctx, s.cur, RC_K_PYR, k, (double)count * ((double)pl.w * pl.h + 4. * n));
             rc_launch_pyr(pa, count, L.pyr_lds, s.cur);
         }
-        RcPolyArgs qa;
         qa.I = (const float*)s.I[k].p; qa.I_slot_stride = n;
-        qa.RA = (float4*)s.RA[k].p; qa.RB = (float*)s.RB[k].p; qa.R_slot_stride = n;
-        qa.slot0 = dslot0; qa.nslots = pl.nslots; qa.w = L.w; qa.h = L.h; qa.pk = pl.pk;
         {
             RcProfScope ps(ctx, s.cur, RC_K_POLY, k, (double)count * 24. * n);
             rc_launch_polyexp(qa, count, s.cur);
@@ -525,8 +526,6 @@ static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_
         a.RA = (const float4*)s.RA[k].p; a.RB = (const float*)s.RB[k].p; a.R_slot_stride = n;
         a.slot0 = slot0; a.slot1 = (slot0 + 1) % pl.nslots; a.nslots = pl.nslots;
         a.w = L.w; a.h = L.h;
-        a.tw = pl.iter_tw; a.th = pl.iter_th;
-        a.tiles_x = (L.w + a.tw - 1) / a.tw; a.tiles_y = (L.h + a.th - 1) / a.th;
         a.win = pl.win;
         const float2* cur_in = nullptr;
         int passes = iters > 0 ? iters : 1;
@@ -713,6 +712,7 @@ extern "C" int rcflow_stage_polyexp_dev(rc_ctx* ctx, int stream, const float* d_
     if ((rc = rc_buf_ensure(s->stage_f32[0], n * sizeof(float4)))) return rc;
     if ((rc = rc_buf_ensure(s->stage_f32[1], n * sizeof(float)))) return rc;
     RcPolyArgs qa;
+    memset(&qa, 0, sizeof(qa));
     qa.I = d_I; qa.I_slot_stride = 0;
     qa.RA = (float4*)s->stage_f32[0].p; qa.RB = (float*)s->stage_f32[1].p; qa.R_slot_stride = 0;
     qa.slot0 = 0; qa.nslots = 1; qa.w = w; qa.h = h;
@@ -739,18 +739,15 @@ extern "C" int rcflow_stage_flow_iter_dev(rc_ctx* ctx, int stream, const float* 
     float* RB = (float*)s->stage_f32[1].p;
     rc_launch_pack_R5(d_R0, RA, RB, (int)n, s->cur);
     rc_launch_pack_R5(d_R1, RA + n, RB + n, (int)n, s->cur);
-    RcPlan tmp;
-    host_window(winsize, flags, tmp.win);
-    pick_iter_tile(tmp);
+    RcWindow win;
+    host_window(winsize, flags, win);
     RcIterArgs a;
     memset(&a, 0, sizeof(a));
     a.RA = RA; a.RB = RB; a.R_slot_stride = n; a.slot0 = 0; a.slot1 = 1; a.nslots = 2;
     a.w = w; a.h = h;
     a.in_mode = d_flow_in ? 1 : 0; a.fin = (const float2*)d_flow_in; a.fin_pair_stride = n;
     a.fout = (char*)d_flow_out; a.fout_step = (size_t)w * 8; a.fout_pair_stride = n * 8;
-    a.tw = tmp.iter_tw; a.th = tmp.iter_th;
-    a.tiles_x = (w + a.tw - 1) / a.tw; a.tiles_y = (h + a.th - 1) / a.th;
-    a.solve = 1; a.win = tmp.win;
+    a.solve = 1; a.win = win;
     rc_launch_flow_iter(a, 1, s->cur);
     RC_HIP(hipGetLastError());
     return RC_OK;

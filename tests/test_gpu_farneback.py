@@ -237,7 +237,7 @@ def test_4k_five_scales_properties(ctx):
     d = torch.as_tensor(clip).cuda()
     z = ctx.calcOpticalFlowFarneback(d[0], d[0], None, **p)
     ctx.sync()
-    assert float(z[:-80, :-80].abs().max()) == 0.0
+    assert float(z[:-200, :-200].abs().max()) == 0.0
     f = ctx.calcOpticalFlowFarneback(d[0], d[1], None, **p).clone()
     fm = ctx.calcOpticalFlowFarneback(d[0].flip(1).contiguous(), d[1].flip(1).contiguous(), None, **p)
     ctx.sync()
