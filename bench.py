@@ -76,6 +76,7 @@ def main():
 
     from ripcurrents_amd import synth
     from ripcurrents_amd.api import Context
+    from ripcurrents_amd.distributed import allreduce_hist_words
 
     params = dict(PARAMS)
     if args.gaussian:
@@ -93,9 +94,8 @@ def main():
         ctx.farneback_clip(frames, flows, **params)
         ctx.histogram_accumulate_clip(flows)
         if world > 1:
-            # global flow histogram: integer sum, order independent
-            g = hist_words.clone()
-            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            # global flow histogram: integer sum over RCCL, order independent
+            allreduce_hist_words(hist_words)
         ctx.thresholds()
 
     for _ in range(args.warmup):

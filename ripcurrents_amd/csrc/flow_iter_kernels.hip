@@ -8,8 +8,8 @@
 // evaluates it for its tile plus the window halo straight into LDS (clamped coordinates =
 // the replicate border of the window), applies the separable window there and solves the
 // 2x2 system in double like upstream.  Upstream's in-loop stripe update (A6) equals
-// "window+solve the whole image, then update all matrices" (tests/test_oracle.py pins
-// that), so one launch of this kernel is one iteration and the intermediate flow of
+// "window+solve the whole image, then update all matrices" (a CPU test pins that
+// equivalence), so one launch of this kernel is one iteration and the intermediate flow of
 // iteration i only exists as this kernel's input for iteration i+1.
 //
 // HBM traffic per pixel: R0 20 B + R1 20 B (gathered; L2 serves the 4x bilinear overlap)
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_flow_iter(RcIterArgs a) {
     const bool gauss = RT ? (a.win.gaussian != 0) : (GAUSS_ != 0);
     const int tid = threadIdx.x;
     const int z = blockIdx.y;
-    const int t = rc_xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y);
+    const int t = a.xcd_remap ? rc_xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y) : (int)blockIdx.x;
     const int tx0 = (t % a.tiles_x) * tw, ty0 = (t / a.tiles_x) * th;
     const int w = a.w, h = a.h;
     const int MW = tw + 2 * m, MH = th + 2 * m, MP = MW | 1;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(RC_W3_THREADS) void k_flow_iter_w3(RcIterArgs a) {
     float* Ms = smf;                    // [5][MH][MP]
     const int tid = threadIdx.x;
     const int z = blockIdx.y;
-    const int t = rc_xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y);
+    const int t = a.xcd_remap ? rc_xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y) : (int)blockIdx.x;
     const int tx0 = (t % a.tiles_x) * TW, ty0 = (t / a.tiles_x) * TH;
     const int w = a.w, h = a.h;
     const size_t s0 = (size_t)((a.slot0 + z) % a.nslots) * a.R_slot_stride;
@@ -303,6 +303,10 @@ __global__ __launch_bounds__(RC_W3_THREADS) void k_flow_iter_w3(RcIterArgs a) {
     const float2* __restrict__ fin = a.fin + (size_t)z * a.fin_pair_stride;
     char* fout = a.fout + (size_t)z * a.fout_pair_stride;
 
+    if (a.ablate & 8) {              // ablation: empty block
+        if (tid == 9999) *(float*)fout = 1.f;
+        return;
+    }
     int gx[NIT], gy[NIT];
 #pragma unroll
     for (int q = 0; q < NIT; q++) {
@@ -361,8 +365,16 @@ __global__ __launch_bounds__(RC_W3_THREADS) void k_flow_iter_w3(RcIterArgs a) {
         const size_t pw = inside[q] ? (size_t)w : 0, p1 = inside[q] ? 1 : 0;
         A0[q] = RA0[p0];
         B0[q] = RB0[p0];
-        q00[q] = RA1[p]; q01[q] = RA1[p + p1]; q10[q] = RA1[p + pw]; q11[q] = RA1[p + pw + p1];
-        e00[q] = RB1[p]; e01[q] = RB1[p + p1]; e10[q] = RB1[p + pw]; e11[q] = RB1[p + pw + p1];
+        if (a.ablate & 1) {          // ablation: no R1 gathers
+            q00[q] = q01[q] = q10[q] = q11[q] = A0[q];
+            e00[q] = e01[q] = e10[q] = e11[q] = B0[q];
+        } else if (a.ablate & 16) {  // ablation: RA1 gathers only
+            q00[q] = RA1[p]; q01[q] = RA1[p + p1]; q10[q] = RA1[p + pw]; q11[q] = RA1[p + pw + p1];
+            e00[q] = e01[q] = e10[q] = e11[q] = B0[q];
+        } else {
+            q00[q] = RA1[p]; q01[q] = RA1[p + p1]; q10[q] = RA1[p + pw]; q11[q] = RA1[p + pw + p1];
+            e00[q] = RB1[p]; e01[q] = RB1[p + p1]; e10[q] = RB1[p + pw]; e11[q] = RB1[p + pw + p1];
+        }
     }
     // ---- FarnebackUpdateMatrices (operation order of optflow.cpp)
 #pragma unroll
@@ -411,6 +423,10 @@ __global__ __launch_bounds__(RC_W3_THREADS) void k_flow_iter_w3(RcIterArgs a) {
         }
     }
     __syncthreads();
+    if (a.ablate & 4) {              // ablation: no window / solve / store
+        if (Ms[tid] == 12345.678f) *(float*)fout = 1.f;
+        return;
+    }
 
     // ---- 3x3 window + solve: lane = column, RPT rows per thread
     constexpr int RPT = TH / (RC_W3_THREADS / TW);
@@ -452,6 +468,245 @@ static void launch_w3(RcIterArgs a, int pairs, hipStream_t s) {
     a.tiles_x = (a.w + 63) / 64; a.tiles_y = (a.h + 15) / 16;
     size_t lds = sizeof(float) * 5 * 18 * 67;
     hipLaunchKernelGGL((k_flow_iter_w3<IN_MODE, G>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(RC_W3_THREADS), lds, s, a);
+}
+
+// ------------------------------------------------------------------------------------
+// TWO iterations in one launch (3x3 window).  Both iterations of a scale read the same R0
+// and R1, and iteration 2 needs iteration 1's flow only at the pixel itself, so a block
+// can run   M0 (tile + 2 halo) -> flow1 (tile + 1 halo) -> M1 -> flow2 (tile)   entirely
+// on chip: R0 stays in registers, flow1 never exists in memory, and R1's second gather
+// (at p + flow1) hits the lines the first one just brought in.  HBM bytes per pixel drop
+// from 2 x 56 to about 56.  Arithmetic is operation-for-operation that of two launches of
+// k_flow_iter_w3 (bit-identical results).
+struct RcGather {
+    float4 q00, q01, q10, q11;
+    float e00, e01, e10, e11;
+    float fx, fy;
+    bool inside;
+};
+
+__device__ __forceinline__ void rc_gather_issue(RcGather& g, const float4* __restrict__ RA1,
+                                                const float* __restrict__ RB1, int gx, int gy, float dx,
+                                                float dy, int w, int h) {
+    float fx = gx + dx, fy = gy + dy;
+    int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    g.fx = fx - x1;
+    g.fy = fy - y1;
+    g.inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+    const size_t p = g.inside ? (size_t)y1 * w + x1 : (size_t)gy * w + gx;
+    const size_t pw = g.inside ? (size_t)w : 0, p1 = g.inside ? 1 : 0;
+    g.q00 = RA1[p]; g.q01 = RA1[p + p1]; g.q10 = RA1[p + pw]; g.q11 = RA1[p + pw + p1];
+    g.e00 = RB1[p]; g.e01 = RB1[p + p1]; g.e10 = RB1[p + pw]; g.e11 = RB1[p + pw + p1];
+}
+
+__device__ __forceinline__ RcM5 rc_matrices_reg(const float4 A0, const float B0, const RcGather& g, float dx,
+                                                float dy, int X, int Y, int w, int h) {
+    float fx = g.fx, fy = g.fy;
+    float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy);
+    float a10 = (1.f - fx) * fy, a11 = fx * fy;
+    float r2 = a00 * g.q00.x + a01 * g.q01.x + a10 * g.q10.x + a11 * g.q11.x;
+    float r3 = a00 * g.q00.y + a01 * g.q01.y + a10 * g.q10.y + a11 * g.q11.y;
+    float r4 = a00 * g.q00.z + a01 * g.q01.z + a10 * g.q10.z + a11 * g.q11.z;
+    float r5 = a00 * g.q00.w + a01 * g.q01.w + a10 * g.q10.w + a11 * g.q11.w;
+    float r6 = a00 * g.e00 + a01 * g.e01 + a10 * g.e10 + a11 * g.e11;
+    r4 = (A0.z + r4) * 0.5f;
+    r5 = (A0.w + r5) * 0.5f;
+    r6 = (B0 + r6) * 0.25f;
+    if (!g.inside) {
+        r2 = r3 = 0.f;
+        r4 = A0.z;
+        r5 = A0.w;
+        r6 = B0 * 0.5f;
+    }
+    r2 = (A0.x - r2) * 0.5f;
+    r3 = (A0.y - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    if ((unsigned)(X - 5) >= (unsigned)(w - 10) || (unsigned)(Y - 5) >= (unsigned)(h - 10)) {
+        float bl = X < 5 ? (X < 2 ? 0.14f : 0.4472f) : 1.f;
+        int rx = w - X - 1;
+        float br = X >= w - 5 ? (rx < 2 ? 0.14f : 0.4472f) : 1.f;
+        float bt = Y < 5 ? (Y < 2 ? 0.14f : 0.4472f) : 1.f;
+        int ry = h - Y - 1;
+        float bb = Y >= h - 5 ? (ry < 2 ? 0.14f : 0.4472f) : 1.f;
+        float scale = bl * br * bt * bb;
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
+    RcM5 o;
+    o.m0 = r4 * r4 + r6 * r6;
+    o.m1 = (r4 + r5) * r6;
+    o.m2 = r5 * r5 + r6 * r6;
+    o.m3 = r4 * r2 + r6 * r3;
+    o.m4 = r6 * r2 + r5 * r3;
+    return o;
+}
+
+// 3x3 window of the five LDS planes around (ly, lx) + solve; same order as k_flow_iter_w3.
+template <int GAUSS_>
+__device__ __forceinline__ float2 rc_window3_solve(const float* Ms, int plane, int pitch, int ly, int lx,
+                                                   const RcWindow& win) {
+    double g[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const float* mc = Ms + c * plane + (ly - 1) * pitch + (lx - 1);
+        float v[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            float up = mc[j], mid = mc[pitch + j], dn = mc[2 * pitch + j];
+            if (GAUSS_) v[j] = mid * win.k[0] + (dn + up) * win.k[1];
+            else v[j] = mid + (dn + up);
+        }
+        if (GAUSS_) g[c] = v[1] * win.k[0] + win.k[1] * (v[0] + v[2]);
+        else g[c] = ((double)v[1] + ((double)v[2] + (double)v[0])) * win.box_scale;
+    }
+    return rc_solve(g);
+}
+
+template <int IN_MODE, int GAUSS_>
+__global__ __launch_bounds__(RC_W3_THREADS, 4) void k_flow_iter2_w3(RcIterArgs a) {
+    constexpr int TW = 64, TH = 16, MW = TW + 4, MH = TH + 4, MP = MW | 1, PLANE = MH * MP;
+    constexpr int NIT = 3, NGRP = (MH + NIT - 1) / NIT;       // a thread owns NIT vertically adjacent pixels
+    static_assert(MW * NGRP <= RC_W3_THREADS, "tile does not fit the block");
+    extern __shared__ __align__(16) float smf[];
+    float* Ms = smf;                    // [5][MH][MP]: M0 (halo 2), later M1 (halo 1) in place
+    const int tid = threadIdx.x;
+    const int z = blockIdx.y;
+    const int t = a.xcd_remap ? rc_xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y) : (int)blockIdx.x;
+    const int tx0 = (t % a.tiles_x) * TW, ty0 = (t / a.tiles_x) * TH;
+    const int w = a.w, h = a.h;
+    const size_t s0 = (size_t)((a.slot0 + z) % a.nslots) * a.R_slot_stride;
+    const size_t s1 = (size_t)((a.slot1 + z) % a.nslots) * a.R_slot_stride;
+    const float4* __restrict__ RA0 = a.RA + s0;  const float* __restrict__ RB0 = a.RB + s0;
+    const float4* __restrict__ RA1 = a.RA + s1;  const float* __restrict__ RB1 = a.RB + s1;
+    const float2* __restrict__ fin = a.fin + (size_t)z * a.fin_pair_stride;
+    char* fout = a.fout + (size_t)z * a.fout_pair_stride;
+
+    const bool owner = tid < MW * NGRP;
+    const int lxo = owner ? tid % MW : 0, ly0 = owner ? (tid / MW) * NIT : 0;
+    const int gxo = rc_clampi(tx0 - 2 + lxo, 0, w - 1);
+    const int lxc = gxo - (tx0 - 2);          // LDS column of the pixel this column replicates
+#define RC_GY(q) rc_clampi(ty0 - 2 + min(ly0 + (q), MH - 1), 0, h - 1)
+    // ---- flow_in
+    float dx[NIT], dy[NIT];
+    if constexpr (IN_MODE == 0) {
+#pragma unroll
+        for (int q = 0; q < NIT; q++) dx[q] = dy[q] = 0.f;
+    } else if constexpr (IN_MODE == 1) {
+        float2 d[NIT];
+#pragma unroll
+        for (int q = 0; q < NIT; q++) d[q] = fin[(size_t)RC_GY(q) * w + gxo];
+#pragma unroll
+        for (int q = 0; q < NIT; q++) { dx[q] = d[q].x; dy[q] = d[q].y; }
+    } else {
+        float2 p00[NIT], p01[NIT], p10[NIT], p11[NIT];
+        float ax, ay[NIT];
+        const int sx = rc_src_x(gxo, a.up_scale_x, a.fin_w, ax);
+        const int sx1 = min(sx + 1, a.fin_w - 1);
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            int sy = rc_src_y(RC_GY(q), a.up_scale_y, ay[q]);
+            int sy0 = rc_clampi(sy, 0, a.fin_h - 1), sy1 = rc_clampi(sy + 1, 0, a.fin_h - 1);
+            const float2* S0 = fin + (size_t)sy0 * a.fin_w;
+            const float2* S1 = fin + (size_t)sy1 * a.fin_w;
+            p00[q] = S0[sx]; p01[q] = S0[sx1]; p10[q] = S1[sx]; p11[q] = S1[sx1];
+        }
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            float a0 = 1.f - ax, a1 = ax, b0 = 1.f - ay[q], b1 = ay[q];
+            float r0x = p00[q].x * a0 + p01[q].x * a1, r1x = p10[q].x * a0 + p11[q].x * a1;
+            float r0y = p00[q].y * a0 + p01[q].y * a1, r1y = p10[q].y * a0 + p11[q].y * a1;
+            dx[q] = (r0x * b0 + r1x * b1) * a.up_mul;
+            dy[q] = (r0y * b0 + r1y * b1) * a.up_mul;
+        }
+    }
+    // ---- iteration 1 matrices: R0 (kept in registers for iteration 2) + gathers
+    float4 A0[NIT];
+    float B0[NIT];
+    {
+        RcGather g[NIT];
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            const int gy = RC_GY(q);
+            size_t p0 = (size_t)gy * w + gxo;
+            A0[q] = RA0[p0];
+            B0[q] = RB0[p0];
+            rc_gather_issue(g[q], RA1, RB1, gxo, gy, dx[q], dy[q], w, h);
+        }
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            RcM5 v = rc_matrices_reg(A0[q], B0[q], g[q], dx[q], dy[q], gxo, RC_GY(q), w, h);
+            if (owner && ly0 + q < MH) {
+                float* mp = Ms + (ly0 + q) * MP + lxo;
+                mp[0] = v.m0; mp[PLANE] = v.m1; mp[2 * PLANE] = v.m2; mp[3 * PLANE] = v.m3; mp[4 * PLANE] = v.m4;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- flow1 at tile + 1 halo (the pixels this thread already owns), then its gathers.
+    // The flow of a halo position outside the image is the flow of the pixel it replicates,
+    // so the window is centred on that pixel's own LDS position.
+    RcM5 m1[NIT];
+    {
+        RcGather g[NIT];
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            const int gy = RC_GY(q);
+            float2 f1 = rc_window3_solve<GAUSS_>(Ms, PLANE, MP, gy - (ty0 - 2), lxc, a.win);
+            dx[q] = f1.x;
+            dy[q] = f1.y;
+            rc_gather_issue(g[q], RA1, RB1, gxo, gy, dx[q], dy[q], w, h);
+        }
+#pragma unroll
+        for (int q = 0; q < NIT; q++)
+            m1[q] = rc_matrices_reg(A0[q], B0[q], g[q], dx[q], dy[q], gxo, RC_GY(q), w, h);
+    }
+    __syncthreads();      // every thread is done reading M0
+#pragma unroll
+    for (int q = 0; q < NIT; q++) {
+        const int ly = ly0 + q;
+        if (owner && lxo >= 1 && lxo <= MW - 2 && ly >= 1 && ly <= MH - 2) {
+            float* mp = Ms + ly * MP + lxo;
+            mp[0] = m1[q].m0; mp[PLANE] = m1[q].m1; mp[2 * PLANE] = m1[q].m2; mp[3 * PLANE] = m1[q].m3;
+            mp[4 * PLANE] = m1[q].m4;
+        }
+    }
+#undef RC_GY
+    __syncthreads();
+    // ---- flow2 on the tile
+    constexpr int RPT = TH / (RC_W3_THREADS / TW);
+    const int lx = tid % TW, r0 = (tid / TW) * RPT;
+    const int ox = tx0 + lx;
+    if (ox < w) {
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            int oy = ty0 + r0 + r;
+            if (oy < h)
+                *(float2*)(fout + (size_t)oy * a.fout_step + (size_t)ox * 8) =
+                    rc_window3_solve<GAUSS_>(Ms, PLANE, MP, r0 + r + 2, lx + 2, a.win);
+        }
+    }
+}
+
+template <int IN_MODE, int G>
+static void launch_w3x2(RcIterArgs a, int pairs, hipStream_t s) {
+    a.tw = 64; a.th = 16;
+    a.tiles_x = (a.w + 63) / 64; a.tiles_y = (a.h + 15) / 16;
+    size_t lds = sizeof(float) * 5 * 20 * 69;
+    hipLaunchKernelGGL((k_flow_iter2_w3<IN_MODE, G>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(RC_W3_THREADS), lds, s, a);
+}
+
+int rc_flow_iter_can_fuse2(const RcIterArgs& a) { return a.win.m == 1 && a.solve; }
+
+void rc_launch_flow_iter2(const RcIterArgs& a, int pairs, hipStream_t s) {
+    const int g = a.win.gaussian ? 1 : 0;
+    switch (a.in_mode * 2 + g) {
+        case 0: launch_w3x2<0, 0>(a, pairs, s); break;
+        case 1: launch_w3x2<0, 1>(a, pairs, s); break;
+        case 2: launch_w3x2<1, 0>(a, pairs, s); break;
+        case 3: launch_w3x2<1, 1>(a, pairs, s); break;
+        case 4: launch_w3x2<2, 0>(a, pairs, s); break;
+        default: launch_w3x2<2, 1>(a, pairs, s); break;
+    }
 }
 
 static size_t iter_lds(int tw, int th, int m, bool two_buffers) {

@@ -165,7 +165,8 @@ __global__ __launch_bounds__(RC_BLOCK) void k_pyr_direct(RcPyrArgs a) {
     const bool aligned = ((((size_t)a.src) | a.src_step | a.src_frame_stride) & 3) == 0;
     const bool fast = aligned && sx1 == sx + 1 && y1 == y0 + 1 && xs >= 0 && xa + 4 * NDW <= W0 &&
                       sx1 + R <= W0 - 1 && y0 - R >= 0 && y1 + R <= H0 - 1;
-    float b00, b01, b10, b11;
+    // row-pass results at columns sx and sx+1 for the NROW virtual source rows y0-R .. y0+R+1
+    float rp0[NROW], rp1[NROW];
     if (fast) {
         unsigned int dw[NROW][NDW];
 #pragma unroll
@@ -174,7 +175,6 @@ __global__ __launch_bounds__(RC_BLOCK) void k_pyr_direct(RcPyrArgs a) {
 #pragma unroll
             for (int j = 0; j < NDW; j++) dw[rr][j] = row[j];
         }
-        float rp0[NROW], rp1[NROW];
 #pragma unroll
         for (int rr = 0; rr < NROW; rr++) {
             float b[NB];
@@ -189,35 +189,47 @@ __global__ __launch_bounds__(RC_BLOCK) void k_pyr_direct(RcPyrArgs a) {
             rp0[rr] = rc_rowpass<R>(b, k);
             rp1[rr] = rc_rowpass<R>(b + 1, k);
         }
-        b00 = k[R] * rp0[R]; b01 = k[R] * rp1[R];
-        b10 = k[R] * rp0[R + 1]; b11 = k[R] * rp1[R + 1];
-#pragma unroll
-        for (int j = 1; j <= R; j++) {
-            b00 += k[R + j] * (rp0[R + j] + rp0[R - j]);
-            b01 += k[R + j] * (rp1[R + j] + rp1[R - j]);
-            b10 += k[R + j] * (rp0[R + 1 + j] + rp0[R + 1 - j]);
-            b11 += k[R + j] * (rp1[R + 1 + j] + rp1[R + 1 - j]);
-        }
     } else {
-        float bv[4];
+        // border footprint: per-byte REFLECT_101 addressing, same virtual rows/columns.  (When
+        // sx+1 is clamped its weight a1 is 0, and when y1 == y0 the second row pair is a copy
+        // of the first, so the virtual column sx+1 / row y0+R+1 only has to be finite.)
+        int cx[NB];
 #pragma unroll
-        for (int pt = 0; pt < 4; pt++) {
-            const int cx = (pt & 1) ? sx1 : sx, cy = (pt & 2) ? y1 : y0;
-            float rp[KS];
-            for (int rr = 0; rr < KS; rr++) {
-                const uint8_t* row = src + (size_t)rc_reflect101(cy - R + rr, H0) * a.src_step;
-                float b[KS];
+        for (int j = 0; j < NB; j++) cx[j] = rc_reflect101(xs + j, W0);
+        constexpr int HALF = (NROW + 1) / 2;
 #pragma unroll
-                for (int j = 0; j < KS; j++) b[j] = (float)row[rc_reflect101(cx - R + j, W0)];
-                rp[rr] = rc_rowpass<R>(b, k);
+        for (int part = 0; part < 2; part++) {
+            unsigned char bytes[HALF][NB];
+#pragma unroll
+            for (int rh = 0; rh < HALF; rh++) {
+                int rr = part * HALF + rh;
+                const uint8_t* row = src + (size_t)rc_reflect101(y0 - R + min(rr, NROW - 1), H0) * a.src_step;
+#pragma unroll
+                for (int j = 0; j < NB; j++) bytes[rh][j] = row[cx[j]];
             }
-            float v = k[R] * rp[R];
 #pragma unroll
-            for (int j = 1; j <= R; j++) v += k[R + j] * (rp[R + j] + rp[R - j]);
-            bv[pt] = v;
+            for (int rh = 0; rh < HALF; rh++) {
+                int rr = part * HALF + rh;
+                if (rr < NROW) {
+                    float b[NB];
+#pragma unroll
+                    for (int j = 0; j < NB; j++) b[j] = (float)bytes[rh][j];
+                    rp0[rr] = rc_rowpass<R>(b, k);
+                    rp1[rr] = rc_rowpass<R>(b + 1, k);
+                }
+            }
         }
-        b00 = bv[0]; b01 = bv[1]; b10 = bv[2]; b11 = bv[3];
     }
+    float b00 = k[R] * rp0[R], b01 = k[R] * rp1[R];
+    float b10 = k[R] * rp0[R + 1], b11 = k[R] * rp1[R + 1];
+#pragma unroll
+    for (int j = 1; j <= R; j++) {
+        b00 += k[R + j] * (rp0[R + j] + rp0[R - j]);
+        b01 += k[R + j] * (rp1[R + j] + rp1[R - j]);
+        b10 += k[R + j] * (rp0[R + 1 + j] + rp0[R + 1 - j]);
+        b11 += k[R + j] * (rp1[R + 1 + j] + rp1[R + 1 - j]);
+    }
+    if (y1 == y0) { b10 = b00; b11 = b01; }
     float a0 = 1.f - ax, a1 = ax, w0 = 1.f - ay, w1 = ay;
     float r0 = b00 * a0 + b01 * a1;
     float r1 = b10 * a0 + b11 * a1;

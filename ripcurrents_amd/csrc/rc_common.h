@@ -92,12 +92,17 @@ struct RcIterArgs {
     int tw, th;               // tile (filled by the launcher)
     int tiles_x, tiles_y;
     int solve;                // 0: write flow_in (iterations == 0), 1: normal
+    int xcd_remap;            // XCD-aware tile order (speed only)
+    int ablate;               // timing-only ablation bits (0 in production)
     RcWindow win;
 };
 
 void rc_launch_pyr(const RcPyrArgs& a, int frames, size_t lds, hipStream_t s);
 void rc_launch_polyexp(const RcPolyArgs& a, int frames, hipStream_t s);
 void rc_launch_flow_iter(const RcIterArgs& a, int pairs, hipStream_t s);
+// two iterations in one launch (only where rc_flow_iter_can_fuse2 says so)
+int rc_flow_iter_can_fuse2(const RcIterArgs& a);
+void rc_launch_flow_iter2(const RcIterArgs& a, int pairs, hipStream_t s);
 
 // interleave helpers for the stage-level test entry points
 void rc_launch_pack_R5(const float* R5, float4* RA, float* RB, int n, hipStream_t s);

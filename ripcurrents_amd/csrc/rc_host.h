@@ -59,6 +59,9 @@ struct rc_ctx {
     RcSlot* slots = nullptr;
     int chunk = 4;
     int exact_taps = 0;
+    int fuse_iters = 1;
+    int xcd_remap = 1;
+    int ablate = 0;
     int prof_on = 0;
     std::vector<RcProfRec> prof_pending;
     std::vector<hipEvent_t> ev_pool;
@@ -67,7 +70,7 @@ struct rc_ctx {
 };
 
 enum { RC_K_PYR = 0, RC_K_POLY = 1, RC_K_ITER = 2, RC_K_HIST = 3, RC_K_THRESH = 4, RC_K_CLASSIFY = 5,
-       RC_K_ADVECT_FIELD = 6, RC_K_ADVECT_POINTS = 7, RC_K_POSTOP = 8, RC_K_COLOR = 9, RC_K_KINDS = 10 };
+       RC_K_ADVECT_FIELD = 6, RC_K_ADVECT_POINTS = 7, RC_K_POSTOP = 8, RC_K_COLOR = 9, RC_K_ITER2 = 10, RC_K_KINDS = 11 };
 
 void rc_set_error(const char* fmt, ...);
 int rc_buf_ensure(RcBuf& b, size_t bytes);

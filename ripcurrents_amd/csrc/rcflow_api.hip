@@ -72,7 +72,7 @@ RcProfScope::~RcProfScope() {
 
 static const char* kKindNames[RC_K_KINDS] = {"pyr_level", "polyexp", "flow_iter", "polar_hist",
                                              "thresholds", "classify_accumulate", "advect_field",
-                                             "advect_points", "flow_postop", "flow_color"};
+                                             "advect_points", "flow_postop", "flow_color", "flow_iter_x2"};
 static char g_names[RC_K_KINDS * RC_MAX_LEVELS][40];
 
 static void prof_resolve(rc_ctx* ctx) {
@@ -222,6 +222,12 @@ extern "C" int rcflow_set_option(rc_ctx* ctx, const char* name, int value) {
         ctx->chunk = value;
     } else if (!strcmp(name, "exact_taps")) {
         ctx->exact_taps = value ? 1 : 0;
+    } else if (!strcmp(name, "fuse_iters")) {
+        ctx->fuse_iters = value ? 1 : 0;
+    } else if (!strcmp(name, "xcd_remap")) {
+        ctx->xcd_remap = value ? 1 : 0;
+    } else if (!strcmp(name, "ablate")) {
+        ctx->ablate = value;
     } else {
         rc_set_error("unknown option %s", name);
         return RC_EINVAL;
@@ -527,9 +533,12 @@ static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_
         a.slot0 = slot0; a.slot1 = (slot0 + 1) % pl.nslots; a.nslots = pl.nslots;
         a.w = L.w; a.h = L.h;
         a.win = pl.win;
+        a.xcd_remap = ctx->xcd_remap;
+        a.ablate = ctx->ablate;
         const float2* cur_in = nullptr;
         int passes = iters > 0 ? iters : 1;
-        for (int i = 0; i < passes; i++) {
+        int nout = 0;   // intermediate buffers written so far at this scale (ping-pong index)
+        for (int i = 0; i < passes;) {
             double in_bytes;
             if (i == 0) {
                 if (!coarse) { a.in_mode = 0; a.fin = nullptr; in_bytes = 0; }
@@ -544,19 +553,25 @@ static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_
             } else {
                 a.in_mode = 1; a.fin = cur_in; a.fin_pair_stride = n; in_bytes = 8. * n;
             }
-            bool last = (i == passes - 1);
+            a.solve = iters > 0 ? 1 : 0;
+            // two iterations per launch whenever two are left and the window allows it
+            int fuse = (passes - i >= 2 && ctx->fuse_iters && rc_flow_iter_can_fuse2(a)) ? 2 : 1;
+            bool last = (i + fuse == passes);
             if (last && k == 0) {
                 a.fout = (char*)d_out; a.fout_step = out_step; a.fout_pair_stride = out_pair_stride;
             } else {
-                float2* dst = (float2*)((i & 1) ? s.FB[k].p : s.FA[k].p);
+                float2* dst = (float2*)((nout & 1) ? s.FB[k].p : s.FA[k].p);
+                nout++;
                 a.fout = (char*)dst; a.fout_step = (size_t)L.w * 8; a.fout_pair_stride = n * 8;
                 cur_in = dst;
             }
-            a.solve = iters > 0 ? 1 : 0;
             {
-                RcProfScope ps(ctx, s.cur, RC_K_ITER, k, (double)pairs * ((a.solve ? 40. : 0.) * n + in_bytes + 8. * n));
-                rc_launch_flow_iter(a, pairs, s.cur);
+                RcProfScope ps(ctx, s.cur, fuse == 2 ? RC_K_ITER2 : RC_K_ITER, k,
+                               (double)pairs * ((a.solve ? 40. : 0.) * n + in_bytes + 8. * n));
+                if (fuse == 2) rc_launch_flow_iter2(a, pairs, s.cur);
+                else rc_launch_flow_iter(a, pairs, s.cur);
             }
+            i += fuse;
         }
         coarse = cur_in;
         cw = L.w; ch = L.h;
@@ -747,7 +762,7 @@ extern "C" int rcflow_stage_flow_iter_dev(rc_ctx* ctx, int stream, const float* 
     a.w = w; a.h = h;
     a.in_mode = d_flow_in ? 1 : 0; a.fin = (const float2*)d_flow_in; a.fin_pair_stride = n;
     a.fout = (char*)d_flow_out; a.fout_step = (size_t)w * 8; a.fout_pair_stride = n * 8;
-    a.solve = 1; a.win = win;
+    a.solve = 1; a.win = win; a.xcd_remap = ctx->xcd_remap;
     rc_launch_flow_iter(a, 1, s->cur);
     RC_HIP(hipGetLastError());
     return RC_OK;

@@ -1,0 +1,103 @@
+"""CPU tests of the drop-in boundary and the host logic (no GPU, no compute calls)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rcflow.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rcflow_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ripcurrents_amd import _lib
+    lib = _lib.load()                       # raises if the HIP extension is not built
+    syms = _declared_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(lib, s), "include/rcflow.h declares %s but librcflow.so does not export it" % s
+        assert s in _lib.SIGNATURES, "%s has no ctypes signature" % s
+    assert set(_lib.SIGNATURES) == set(syms)
+    assert lib.rcflow_abi_version() == 1
+
+
+def test_no_device_fails_loudly_never_falls_back():
+    """Without a GPU rcflow_create returns RC_ENODEV and the Python host refuses to run:
+    there is no CPU fallback in the product path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ripcurrents_amd import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    rc = lib.rcflow_create(ctypes.byref(h), 0, 640, 480, 1)
+    assert rc == -4 and not h.value
+    assert b"HIP device" in lib.rcflow_last_error()
+    from ripcurrents_amd.api import Context
+    with pytest.raises(RuntimeError):
+        Context(640, 480)
+    assert lib.rcflow_create(ctypes.byref(h), 0, -1, 480, 1) == -1
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under ripcurrents_amd/ may reference it."""
+    for base, _, files in os.walk(os.path.join(ROOT, "ripcurrents_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(base, f)).read()
+                for pat in ("import oracle", "from oracle", "liboracle", "rc_oracle.h", "oracle/", "oracle."):
+                    assert pat not in text, "%s references the oracle (%s)" % (os.path.join(base, f), pat)
+    out = subprocess.run(["ldd", os.path.join(ROOT, "ripcurrents_amd", "librcflow.so")], capture_output=True, text=True).stdout
+    assert "liboracle" not in out
+
+
+def test_level_geometry_entry_point_matches_oracle(orc):
+    from ripcurrents_amd import _lib
+    lib = _lib.load()
+    for (w, h, ps, lv) in [(1920, 1080, 0.5, 2), (3840, 2160, 0.5, 4), (640, 480, 0.5, 2), (500, 375, 0.8, 6), (40, 36, 0.5, 3)]:
+        for k in range(0, 7):
+            wk, hk = ctypes.c_int(), ctypes.c_int()
+            L = lib.rcflow_level_geometry(w, h, ps, lv, k, ctypes.byref(wk), ctypes.byref(hk))
+            g = orc.level_geometry(w, h, ps, lv, k)
+            assert (L, wk.value, hk.value) == (g["levels"], g["w"], g["h"])
+    assert lib.rcflow_level_geometry(640, 480, 1.0, 2, 0, None, None) == -1
+
+
+def test_synthetic_clips_are_deterministic():
+    from ripcurrents_amd import synth
+    a = synth.surf_clip(160, 120, 3, seed=1234)
+    b = synth.surf_clip(160, 120, 3, seed=1234)
+    assert a.dtype == np.uint8 and a.shape == (3, 120, 160) and np.array_equal(a, b)
+    assert not np.array_equal(a, synth.surf_clip(160, 120, 3, seed=1235))
+    assert 100 < a.mean() < 156 and 20 < a.std() < 60
+    t = synth.translating_clip(64, 48, 2)
+    assert t.shape == (2, 48, 64)
+    f = synth.rotation_field(640, 480)
+    assert f[200, 200, 0] == np.float32(-(200 - 240.0) / 480 * 100)      # main.cpp:376
+
+
+def test_bench_byte_model_matches_survey():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.survey_model_bytes_per_frame(1920, 1080, 2, 2) == 544838400      # 544.84 MB
+    assert bench.survey_model_bytes_per_frame(1920, 1080, 2, 3) == 762566400      # 762.57 MB
+
+
+def test_segment_bounds_cover_the_clip():
+    from ripcurrents_amd.distributed import segment_bounds
+    for nframes in (2, 9, 64, 65):
+        for world in (1, 2, 3, 8):
+            pairs = []
+            for r in range(world):
+                a, b = segment_bounds(nframes, world, r)
+                pairs += [(t, t + 1) for t in range(a, b - 1)]
+            assert pairs == [(t, t + 1) for t in range(nframes - 1)]

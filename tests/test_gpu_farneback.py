@@ -262,3 +262,38 @@ def test_error_codes(ctx):
     with pytest.raises(RcflowError) as e:
         ctx.calcOpticalFlowFarneback(big, big, None, **RC215)
     assert e.value.code == -5
+
+
+@pytest.mark.parametrize("p", [RC215, MAIN264, dict(RC215, iterations=3), dict(RC215, iterations=5, levels=1)])
+def test_fused_iterations_bit_identical(ctx, p):
+    """Two iterations per launch (default) vs one launch per iteration: same bits."""
+    clip = synth.surf_clip(333, 251, 2, seed=8)
+    a = ctx.calcOpticalFlowFarneback(clip[0], clip[1], None, **p)
+    ctx.set_option("fuse_iters", 0)
+    try:
+        b = ctx.calcOpticalFlowFarneback(clip[0], clip[1], None, **p)
+    finally:
+        ctx.set_option("fuse_iters", 1)
+    assert np.array_equal(a, b)
+
+
+def test_against_committed_golden_fixtures(ctx):
+    """tests/golden/*.npz (inputs + oracle outputs, made by tests/golden/make_golden.py)."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, minfrac in (("farneback_rc215_96x80.npz", 0.99), ("farneback_main1119_96x80.npz", 0.99)):
+        g = np.load(os.path.join(gold, name))
+        got = ctx.calcOpticalFlowFarneback(g["prev"], g["next"], None, g["pyr_scale"].item(), g["levels"].item(),
+                                           g["winsize"].item(), g["iters"].item(), g["poly_n"].item(),
+                                           g["poly_sigma"].item(), g["flags"].item())
+        st = _report("golden " + name, got, g["flow"])
+        assert st["frac_1e3"] >= minfrac
+    from ripcurrents_amd.api import HistState
+    h = np.load(os.path.join(gold, "histogram_96x80.npz"))
+    st = HistState()
+    ctx.analysis_reset(96, 80)
+    ctx.create_histogram(h["flow"], st)
+    assert np.array_equal(st.hist, h["hist"]) and np.array_equal(st.hist2d, h["hist2d"])
+    assert st.histsum == h["histsum"].item() and np.array_equal(st.histsum2d, h["histsum2d"])
+    assert st.UPPER == h["UPPER"].item() and np.array_equal(st.UPPER2d, h["UPPER2d"])
+    assert np.array_equal(st.prop_above_upper, h["prop_above_upper"], equal_nan=True)
