@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=32, help="frame pairs (flow fields) per step")
     ap.add_argument("--chunk", type=int, default=0, help="pairs per launch (0 = library default)")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="bracket every kernel of every Nth timed step with HIP events (1 = every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=6)
     ap.add_argument("--gaussian", action="store_true", help="main.cpp:264 variant (flags=256)")
@@ -101,14 +103,18 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if not args.no_kernel_events:
+    events = not args.no_kernel_events
+    if events:
         ctx.profile_reset()
-        ctx.profile_enable(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        # HIP events on the kernels' own stream, inside the timed region; sampled steps only,
+        # because an event pair between two kernels keeps them from overlapping at all
+        if events:
+            ctx.profile_enable(i % args.event_every == 0)
         step()
     torch.cuda.synchronize()
     if world > 1:
@@ -120,7 +126,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     prof = []
-    if not args.no_kernel_events:
+    if events:
         ctx.profile_enable(False)
         prof = ctx.profile_read()
 

@@ -1,0 +1,214 @@
+// rcflow_module.hpp -- C++ host-side mirror of the reference's interface for the hot path,
+// over the C ABI of librcflow (include/rcflow.h).  Header-only; needs the HIP runtime API
+// for host<->device copies (compile with hipcc, or g++ -D__HIP_PLATFORM_AMD__
+// -I/opt/rocm/include ... -lamdhip64 -lrcflow).
+//
+// Names, argument order and meaning follow /root/reference/RipCurrents_main:
+//   calcOpticalFlowFarneback   the cv:: call at ripcurrents.cpp:215, main.cpp:264,...
+//   create_histogram           ripcurrents.hpp:39   ripcurrents_module.cpp:89-144
+//   create_flow                ripcurrents.hpp:50   ripcurrents_module.cpp:153-182
+//   create_accumulationbuffer  ripcurrents.hpp:52   ripcurrents_module.cpp:189-212
+//   streamline_field           ripcurrents.hpp:22   ripcurrents_module.cpp:608-648
+//   streamline                 ripcurrents.hpp:23   ripcurrents_module.cpp:486-528
+//   Streakline                 Streakline.hpp:8-20  Streakline.cpp:11-71
+// rc::Mat is a non-owning view with cv::Mat's fields (data, step, rows, cols); with OpenCV
+// present, include/rcflow_cv.hpp converts cv::Mat to it.  Errors are thrown as
+// rc::Error (the reference's OpenCV calls throw cv::Exception and are never caught).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rcflow.h"
+
+namespace rc {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+inline void check(int rc) {
+    if (rc < 0) throw Error(rc, std::string("rcflow error ") + std::to_string(rc) + ": " + rcflow_last_error());
+}
+inline void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw Error(RC_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// cv::Mat-compatible view of host memory (interleaved channels, byte step).
+struct Mat {
+    void* data = nullptr;
+    size_t step = 0;
+    int rows = 0, cols = 0;
+    int channels = 1, elem = 1;   // elem = bytes per channel
+    Mat() = default;
+    Mat(int r, int c, int ch, int el, void* d, size_t st = 0)
+        : data(d), step(st ? st : (size_t)c * ch * el), rows(r), cols(c), channels(ch), elem(el) {}
+    size_t row_bytes() const { return (size_t)cols * channels * elem; }
+    bool empty() const { return !data || rows <= 0 || cols <= 0; }
+};
+
+typedef struct { float x, y; } Pixel2;   // cv::Point_<float> (ripcurrents.hpp:19)
+
+// One stream slot of one GPU context plus the device copies the module functions work on.
+// The flow field stays resident on the device between calcOpticalFlowFarneback and the
+// analysis calls, like `current` does on the host in ripcurrents.cpp:221-440.
+class Pipeline {
+  public:
+    Pipeline(int xdim, int ydim, int device = 0) : w_(xdim), h_(ydim) {
+        check(rcflow_create(&ctx_, device, xdim, ydim, 1));
+        try {
+            hip_check(hipMalloc(&d_frames_, (size_t)2 * w_ * h_), "hipMalloc frames");
+            hip_check(hipMalloc(&d_flow_, (size_t)w_ * h_ * 8), "hipMalloc flow");
+            hip_check(hipMalloc(&d_mask_, (size_t)w_ * h_), "hipMalloc mask");
+            check(rcflow_analysis_reset(ctx_, 0, w_, h_));
+        } catch (...) {
+            release();
+            throw;
+        }
+    }
+    ~Pipeline() { release(); }
+    Pipeline(const Pipeline&) = delete;
+    Pipeline& operator=(const Pipeline&) = delete;
+
+    rc_ctx* context() { return ctx_; }
+    const float* device_flow() const { return (const float*)d_flow_; }
+
+    // cv::calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, iterations,
+    // poly_n, poly_sigma, flags): 8UC1 in, CV_32FC2 out (flow.data may be null: the field then
+    // only stays resident for the analysis calls).
+    void calcOpticalFlowFarneback(const Mat& prev, const Mat& next, Mat& flow, double pyr_scale, int levels,
+                                  int winsize, int iterations, int poly_n, double poly_sigma, int flags) {
+        if (prev.empty() || next.empty() || prev.rows != next.rows || prev.cols != next.cols ||
+            prev.channels != 1 || prev.elem != 1 || prev.cols != w_ || prev.rows != h_)
+            throw Error(RC_EINVAL, "calcOpticalFlowFarneback: prev/next must be 8UC1 of the pipeline's size");
+        uint8_t* df = (uint8_t*)d_frames_;
+        hip_check(hipMemcpy2D(df, w_, prev.data, prev.step, w_, h_, hipMemcpyHostToDevice), "upload prev");
+        hip_check(hipMemcpy2D(df + (size_t)w_ * h_, w_, next.data, next.step, w_, h_, hipMemcpyHostToDevice), "upload next");
+        rc_farneback_params p = {pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags};
+        check(rcflow_farneback_dev(ctx_, 0, df, w_, df + (size_t)w_ * h_, w_, w_, h_, (float*)d_flow_, (size_t)w_ * 8, &p));
+        check(rcflow_sync(ctx_, 0));
+        if (flow.data) {
+            if (flow.rows != h_ || flow.cols != w_ || flow.channels != 2 || flow.elem != 4)
+                throw Error(RC_EINVAL, "flow must be CV_32FC2 of the frame size");
+            hip_check(hipMemcpy2D(flow.data, flow.step, d_flow_, (size_t)w_ * 8, (size_t)w_ * 8, h_, hipMemcpyDeviceToHost), "download flow");
+        }
+    }
+
+    // Replace the resident flow field (e.g. after host-side edits of `current`).
+    void upload_flow(const Mat& current) {
+        if (current.rows != h_ || current.cols != w_ || current.channels != 2 || current.elem != 4)
+            throw Error(RC_EINVAL, "current must be CV_32FC2 of the frame size");
+        hip_check(hipMemcpy2D(d_flow_, (size_t)w_ * 8, current.data, current.step, (size_t)w_ * 8, h_, hipMemcpyHostToDevice), "upload flow");
+    }
+
+    // create_histogram(current, hist, histsum, hist2d, histsum2d, UPPER, UPPER2d, prop_above_upper)
+    // on the resident flow field.  The counters are cumulative in the slot (never reset by the
+    // reference); the arrays receive their current values.
+    void create_histogram(int hist[RC_HIST_BINS], int& histsum, int hist2d[RC_HIST_DIRECTIONS][RC_HIST_BINS],
+                          int histsum2d[RC_HIST_DIRECTIONS], float& UPPER, float UPPER2d[RC_HIST_DIRECTIONS],
+                          float prop_above_upper[RC_HIST_DIRECTIONS]) {
+        check(rcflow_histogram_dev(ctx_, 0, (const float*)d_flow_, (size_t)w_ * 8, w_, h_));
+        check(rcflow_thresholds_dev(ctx_, 0));
+        int32_t hs = 0;
+        check(rcflow_histogram_read(ctx_, 0, hist, &hist2d[0][0], &hs, histsum2d, &UPPER, UPPER2d, prop_above_upper));
+        histsum = hs;
+    }
+
+    // create_flow + create_accumulationbuffer in one pass; outmask (8UC1, may be null view)
+    // receives the wave mask.  UPPER / UPPER2d are the slot's (from create_histogram).
+    void create_flow_and_accumulationbuffer(Mat& outmask, int framecount, float MID = 0.5f, float LOWER = 0.2f) {
+        check(rcflow_classify_accumulate_dev(ctx_, 0, (const float*)d_flow_, (size_t)w_ * 8, w_, h_, framecount, MID,
+                                             LOWER, nullptr, 0, nullptr, 0, nullptr, 0, (uint8_t*)d_mask_, w_));
+        check(rcflow_sync(ctx_, 0));
+        if (outmask.data)
+            hip_check(hipMemcpy2D(outmask.data, outmask.step, d_mask_, w_, w_, h_, hipMemcpyDeviceToHost), "download mask");
+    }
+    void accumulator(float* acc_x) { check(rcflow_accumulator_read(ctx_, 0, acc_x)); }
+
+    // streamlines_mat.forEach(streamline_field(&pixel, distance, x, y, current, dt, iterations,
+    // UPPER, prop_above_upper)) -- ripcurrents.cpp:229-231.  UPPER < 0: the slot's UPPER.
+    void streamline_field(float dt, int iterations, float UPPER = -1.f) {
+        check(rcflow_advect_field_dev(ctx_, 0, (const float*)d_flow_, (size_t)w_ * 8, w_, h_, dt, iterations, UPPER));
+    }
+    void streamline_field_state(Pixel2* streamlines_mat, float* streamlines_distance) {
+        check(rcflow_advect_field_read(ctx_, 0, (float*)streamlines_mat, streamlines_distance));
+    }
+
+    // for (s...) streamline(streampt + s, color, current, overlay, dt, iterations, UPPER, ...):
+    // advances the seeds; `trace` (optional, n*iterations points) is what the host draws with
+    // cv::line.  variant: see rcflow_advect_points_dev.
+    void streamline(Pixel2* streampt, int n, float dt, int iterations, float UPPER, int variant = 0,
+                    std::vector<Pixel2>* trace = nullptr) {
+        if (n <= 0) return;
+        const int iters = variant == 2 ? 100 : iterations;
+        void *d_pts = nullptr, *d_tr = nullptr;
+        hip_check(hipMalloc(&d_pts, (size_t)n * 8), "hipMalloc seeds");
+        if (trace) hip_check(hipMalloc(&d_tr, (size_t)n * iters * 8), "hipMalloc trace");
+        hip_check(hipMemcpy(d_pts, streampt, (size_t)n * 8, hipMemcpyHostToDevice), "upload seeds");
+        int rc = rcflow_advect_points_dev(ctx_, 0, (float*)d_pts, n, (const float*)d_flow_, (size_t)w_ * 8, w_, h_, dt,
+                                          iterations, UPPER, variant, (float*)d_tr);
+        if (rc == RC_OK) rc = rcflow_sync(ctx_, 0);
+        if (rc == RC_OK) {
+            (void)hipMemcpy(streampt, d_pts, (size_t)n * 8, hipMemcpyDeviceToHost);
+            if (trace) {
+                trace->resize((size_t)n * iters);
+                (void)hipMemcpy(trace->data(), d_tr, (size_t)n * iters * 8, hipMemcpyDeviceToHost);
+            }
+        }
+        (void)hipFree(d_pts);
+        if (d_tr) (void)hipFree(d_tr);
+        check(rc);
+    }
+
+    int width() const { return w_; }
+    int height() const { return h_; }
+
+  private:
+    void release() {
+        if (d_frames_) (void)hipFree(d_frames_);
+        if (d_flow_) (void)hipFree(d_flow_);
+        if (d_mask_) (void)hipFree(d_mask_);
+        d_frames_ = d_flow_ = d_mask_ = nullptr;
+        if (ctx_) rcflow_destroy(ctx_);
+        ctx_ = nullptr;
+    }
+    rc_ctx* ctx_ = nullptr;
+    int w_, h_;
+    void *d_frames_ = nullptr, *d_flow_ = nullptr, *d_mask_ = nullptr;
+};
+
+// Streakline.hpp:8-20.  runLK's bookkeeping (Streakline.cpp:22-71) with the vertices moved
+// through the dense flow field resident in the pipeline (the main.cpp:961-977 precedent)
+// instead of sparse PyrLK; drawing stays with the caller.
+class Streakline {
+  public:
+    int numberOfVertices;
+    Pixel2 generationPoint;
+    std::vector<Pixel2> vertices;
+    int frameCount;
+
+    explicit Streakline(Pixel2 pixel) : numberOfVertices(1), generationPoint(pixel), frameCount(1) {
+        vertices.push_back(pixel);
+    }
+
+    void run(Pipeline& pipe, float dt = 1.f) {
+        std::vector<Pixel2> next = vertices;
+        pipe.streamline(next.data(), (int)next.size(), dt, 1, 0.f, /*variant=*/4);
+        for (size_t i = 0; i < next.size(); i++)   // eliminate any large movement (Streakline.cpp:35-40)
+            if (std::fabs(vertices[i].x - next[i].x) > pipe.width() * 0.1 ||
+                std::fabs(vertices[i].y - next[i].y) > pipe.height() * 0.1)
+                next[i] = vertices[i];
+        vertices = next;
+        vertices.insert(vertices.begin(), generationPoint);   // frameCount % 1 == 0 (Streakline.cpp:46-48)
+        numberOfVertices = (int)vertices.size();
+        frameCount++;
+    }
+};
+
+}  // namespace rc

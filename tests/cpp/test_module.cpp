@@ -1,0 +1,99 @@
+// C++ test of the host mirror (include/rcflow_module.hpp) against the CPU oracle, reading like
+// the reference's frame loop (ripcurrents.cpp:194-440).  Built by __graft_entry__.build()
+// (hipcc), run on the GPU box by tests/test_gpu_cpp_module.py.  Links the oracle as checker.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/rcflow_module.hpp"
+#include "../../oracle/rc_oracle.h"
+
+#define XDIM 320
+#define YDIM 240
+#define REQUIRE(c)                                                        \
+    do {                                                                  \
+        if (!(c)) { printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } \
+    } while (0)
+
+static void make_frame(std::vector<uint8_t>& f, int t) {   // moving smooth texture
+    f.resize((size_t)XDIM * YDIM);
+    for (int y = 0; y < YDIM; y++)
+        for (int x = 0; x < XDIM; x++) {
+            double u = x - 1.25 * t, v = y + 0.75 * t;
+            double s = 128 + 40 * std::sin(u / 7.0) * std::cos(v / 9.0) + 30 * std::sin((u + v) / 13.0) +
+                       20 * std::cos(u / 3.1 - v / 4.3);
+            f[(size_t)y * XDIM + x] = (uint8_t)std::lrint(std::fmin(255.0, std::fmax(0.0, s)));
+        }
+}
+
+int main() {
+    rc::Pipeline pipe(XDIM, YDIM);
+    std::vector<uint8_t> f1, f2;
+    make_frame(f2, 0);
+    // state of ripcurrents.cpp:133-176
+    int hist[RC_HIST_BINS] = {0}, histsum = 0, hist2d[RC_HIST_DIRECTIONS][RC_HIST_BINS] = {{0}}, histsum2d[RC_HIST_DIRECTIONS] = {0};
+    float UPPER = 100.0f, UPPER2d[RC_HIST_DIRECTIONS] = {0}, prop[RC_HIST_DIRECTIONS] = {0};
+    int ohist[RC_HIST_BINS] = {0}, ohistsum = 0, ohist2d[RC_HIST_DIRECTIONS * RC_HIST_BINS] = {0}, ohistsum2d[RC_HIST_DIRECTIONS] = {0};
+    float oUPPER = 100.0f, oUPPER2d[RC_HIST_DIRECTIONS] = {0}, oprop[RC_HIST_DIRECTIONS] = {0};
+    std::vector<float> flow((size_t)XDIM * YDIM * 2), oflow(flow.size()), polar((size_t)XDIM * YDIM * 3);
+    std::vector<float> opt((size_t)XDIM * YDIM * 2, 0.f), odist((size_t)XDIM * YDIM, 0.f);
+    std::vector<float> acc((size_t)XDIM * YDIM * 3, 0.f);
+    std::vector<uint8_t> mask((size_t)XDIM * YDIM), omask(mask.size());
+    rc::Streakline streak(rc::Pixel2{160.f, 120.f});
+    std::vector<float> overts(2 * 64, 0.f);
+    overts[0] = 160.f; overts[1] = 120.f;
+    int on = 1, ofc = 1;
+
+    for (int framecount = 1; framecount <= 4; framecount++) {
+        make_frame(f1, framecount);
+        rc::Mat prev(YDIM, XDIM, 1, 1, f2.data()), next(YDIM, XDIM, 1, 1, f1.data()), mflow(YDIM, XDIM, 2, 4, flow.data());
+        pipe.calcOpticalFlowFarneback(prev, next, mflow, 0.5, 2, 3, 2, 15, 1.2, 0);       // ripcurrents.cpp:215
+        REQUIRE(orc_farneback_u8(f2.data(), XDIM, f1.data(), XDIM, XDIM, YDIM, oflow.data(), XDIM * 8, 0.5, 2, 3, 2, 15, 1.2, 0, 1) == 0);
+        size_t good = 0;
+        for (size_t i = 0; i < flow.size(); i += 2)
+            good += std::fabs(flow[i] - oflow[i]) <= 1e-3f && std::fabs(flow[i + 1] - oflow[i + 1]) <= 1e-3f;
+        REQUIRE(good >= (size_t)(0.99 * XDIM * YDIM));
+        f2 = f1;                                                                             // u_f1.copyTo(u_f2)
+
+        // from here both sides consume the GPU flow field, so everything must agree exactly
+        pipe.streamline_field(2.f, 1);                                                       // ripcurrents.cpp:229-231
+        orc_streamline_field(opt.data(), XDIM * 8, odist.data(), XDIM * 4, flow.data(), XDIM * 8, XDIM, YDIM, 2.f, 1, oUPPER);
+        streak.run(pipe);
+        orc_streakline_step(overts.data(), &on, 160.f, 120.f, flow.data(), XDIM * 8, XDIM, YDIM, 1.f, &ofc);
+
+        pipe.create_histogram(hist, histsum, hist2d, histsum2d, UPPER, UPPER2d, prop);       // ripcurrents.cpp:319-366
+        orc_flow_to_polar(flow.data(), XDIM * 8, XDIM, YDIM, polar.data(), XDIM * 12);
+        orc_histogram_accumulate(polar.data(), XDIM * 12, XDIM, YDIM, ohist, &ohistsum, ohist2d, ohistsum2d);
+        orc_histogram_thresholds(ohist, ohistsum, ohist2d, ohistsum2d, &oUPPER, oUPPER2d, oprop);
+        REQUIRE(histsum == ohistsum && UPPER == oUPPER);
+        for (int d = 0; d < RC_HIST_DIRECTIONS; d++) {
+            REQUIRE(histsum2d[d] == ohistsum2d[d] && UPPER2d[d] == oUPPER2d[d]);
+            for (int b = 0; b < RC_HIST_BINS; b++) REQUIRE(hist2d[d][b] == ohist2d[d * RC_HIST_BINS + b]);
+        }
+
+        rc::Mat mmask(YDIM, XDIM, 1, 1, mask.data());
+        pipe.create_flow_and_accumulationbuffer(mmask, framecount + 30);                     // ripcurrents.cpp:376-439
+        std::vector<float> wc((size_t)XDIM * YDIM * 3, 0.f), acc2(wc.size(), 0.f), out(wc.size(), 0.f);
+        std::fill(omask.begin(), omask.end(), 0);
+        orc_create_flow(polar.data(), XDIM * 12, wc.data(), XDIM * 12, acc2.data(), XDIM * 12, XDIM, YDIM, oUPPER, 0.5f, 0.2f, oUPPER2d);
+        orc_create_accumulationbuffer(acc.data(), XDIM * 12, acc2.data(), XDIM * 12, out.data(), XDIM * 12, omask.data(), XDIM, XDIM, YDIM, framecount + 30);
+        REQUIRE(mask == omask);
+    }
+    std::vector<rc::Pixel2> pt((size_t)XDIM * YDIM);
+    std::vector<float> dist((size_t)XDIM * YDIM);
+    pipe.streamline_field_state(pt.data(), dist.data());
+    for (size_t i = 0; i < dist.size(); i++) REQUIRE(pt[i].x == opt[2 * i] && pt[i].y == opt[2 * i + 1] && dist[i] == odist[i]);
+    REQUIRE(streak.numberOfVertices == on && streak.frameCount == ofc);
+    for (int i = 0; i < on; i++) REQUIRE(streak.vertices[i].x == overts[2 * i] && streak.vertices[i].y == overts[2 * i + 1]);
+
+    // error behaviour: bad arguments throw (the reference's cv:: calls throw cv::Exception)
+    bool threw = false;
+    try {
+        rc::Mat prev(YDIM, XDIM, 1, 1, f2.data()), bad;
+        pipe.calcOpticalFlowFarneback(prev, prev, bad, 1.5, 2, 3, 2, 15, 1.2, 0);
+    } catch (const rc::Error& e) { threw = e.code == RC_EINVAL; }
+    REQUIRE(threw);
+    printf("test_module: ok\n");
+    return 0;
+}
