@@ -114,6 +114,18 @@ __device__ __forceinline__ float2 rc_solve(const double* g) {
     return f;
 }
 
+// 2x2 solve from the UNSCALED window sums: with every g multiplied by s = 1/winsize^2 the
+// factor s^2 cancels except in the +1e-3 regulariser, so eps = 1e-3 / s^2 is used instead.
+// The differences of products (they cancel) are formed in double; the final division is an
+// fp32 reciprocal (1 ulp), far inside the parity tolerance.
+__device__ __forceinline__ float2 rc_solve3(const float* g, double eps) {
+    double g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4];
+    float det = (float)(g0 * g2 - g1 * g1 + eps);
+    float nx = (float)(g0 * g4 - g1 * g3), ny = (float)(g2 * g3 - g1 * g4);
+    float idet = __builtin_amdgcn_rcpf(det);
+    return make_float2(nx * idet, ny * idet);
+}
+
 // TW, TH, M compile-time (TW = TH = 0: runtime values from the arguments).
 template <int TW_, int TH_, int M_, int GAUSS_>
 __global__ __launch_bounds__(RC_BLOCK) void k_flow_iter(RcIterArgs a) {
@@ -432,7 +444,7 @@ __global__ __launch_bounds__(RC_W3_THREADS) void k_flow_iter_w3(RcIterArgs a) {
     constexpr int RPT = TH / (RC_W3_THREADS / TW);
     const int lx = tid % TW, r0 = (tid / TW) * RPT;
     const int ox = tx0 + lx;
-    double g[RPT][5];
+    float g[RPT][5];
 #pragma unroll
     for (int c = 0; c < 5; c++) {
         const float* mc = Ms + c * MH * MP + r0 * MP + lx;
@@ -450,14 +462,16 @@ __global__ __launch_bounds__(RC_W3_THREADS) void k_flow_iter_w3(RcIterArgs a) {
                 else v[j] = col[j][r + 1] + (col[j][r + 2] + col[j][r]);
             }
             if (GAUSS_) g[r][c] = v[1] * a.win.k[0] + a.win.k[1] * (v[0] + v[2]);
-            else g[r][c] = ((double)v[1] + ((double)v[2] + (double)v[0])) * a.win.box_scale;
+            else g[r][c] = v[1] + (v[2] + v[0]);
         }
     }
     if (ox < w) {
 #pragma unroll
         for (int r = 0; r < RPT; r++) {
             int oy = ty0 + r0 + r;
-            if (oy < h) *(float2*)(fout + (size_t)oy * a.fout_step + (size_t)ox * 8) = rc_solve(g[r]);
+            if (oy < h)
+                *(float2*)(fout + (size_t)oy * a.fout_step + (size_t)ox * 8) =
+                    rc_solve3(g[r], GAUSS_ ? 1e-3 : a.win.box_eps);
         }
     }
 }
@@ -541,11 +555,11 @@ __device__ __forceinline__ RcM5 rc_matrices_reg(const float4 A0, const float B0,
     return o;
 }
 
-// 3x3 window of the five LDS planes around (ly, lx) + solve; same order as k_flow_iter_w3.
+// 3x3 window of the five LDS planes around (ly, lx) + solve.
 template <int GAUSS_>
 __device__ __forceinline__ float2 rc_window3_solve(const float* Ms, int plane, int pitch, int ly, int lx,
                                                    const RcWindow& win) {
-    double g[5];
+    float g[5];
 #pragma unroll
     for (int c = 0; c < 5; c++) {
         const float* mc = Ms + c * plane + (ly - 1) * pitch + (lx - 1);
@@ -557,18 +571,61 @@ __device__ __forceinline__ float2 rc_window3_solve(const float* Ms, int plane, i
             else v[j] = mid + (dn + up);
         }
         if (GAUSS_) g[c] = v[1] * win.k[0] + win.k[1] * (v[0] + v[2]);
-        else g[c] = ((double)v[1] + ((double)v[2] + (double)v[0])) * win.box_scale;
+        else g[c] = v[1] + (v[2] + v[0]);
     }
-    return rc_solve(g);
+    return rc_solve3(g, GAUSS_ ? 1e-3 : win.box_eps);
 }
 
-template <int IN_MODE, int GAUSS_>
-__global__ __launch_bounds__(RC_W3_THREADS, 4) void k_flow_iter2_w3(RcIterArgs a) {
-    constexpr int TW = 64, TH = 16, MW = TW + 4, MH = TH + 4, MP = MW | 1, PLANE = MH * MP;
+// Direct global -> LDS load (no VGPR destination).  `lds_wave_base` is the LDS address for lane 0
+// of the wave; lane l lands at lds_wave_base + l * BYTES.
+// (the size argument of the builtin must be a literal)
+__device__ __forceinline__ void rc_glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void rc_glds4(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
+// Bilinear gather of the 5 coefficients of R1 at p + flow: from the block's LDS window when
+// the 2x2 footprint lies inside it (|flow| < D), else from global memory.
+template <int WW, int WH>
+__device__ __forceinline__ void rc_gather_window(RcGather& g, const float4* LA, const float* LB, int ox, int oy,
+                                                 const float4* __restrict__ RA1, const float* __restrict__ RB1,
+                                                 int gx, int gy, float dx, float dy, int w, int h) {
+    float fx = gx + dx, fy = gy + dy;
+    int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    g.fx = fx - x1;
+    g.fy = fy - y1;
+    g.inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+    const int wx = x1 - ox, wy = y1 - oy;
+    if (g.inside && (unsigned)wx < (unsigned)(WW - 1) && (unsigned)wy < (unsigned)(WH - 1)) {
+        const int i = wy * WW + wx;
+        g.q00 = LA[i]; g.q01 = LA[i + 1]; g.q10 = LA[i + WW]; g.q11 = LA[i + WW + 1];
+        g.e00 = LB[i]; g.e01 = LB[i + 1]; g.e10 = LB[i + WW]; g.e11 = LB[i + WW + 1];
+    } else {
+        const size_t p = g.inside ? (size_t)y1 * w + x1 : (size_t)gy * w + gx;
+        const size_t pw = g.inside ? (size_t)w : 0, p1 = g.inside ? 1 : 0;
+        g.q00 = RA1[p]; g.q01 = RA1[p + p1]; g.q10 = RA1[p + pw]; g.q11 = RA1[p + pw + p1];
+        g.e00 = RB1[p]; g.e01 = RB1[p + p1]; g.e10 = RB1[p + pw]; g.e11 = RB1[p + pw + p1];
+    }
+}
+
+// D = half-width of the R1 window beyond the tile+halo region: displacements |flow| < D are
+// served from LDS.  One block = ONE memory round trip: flow_in, R0 and the R1 window do not
+// depend on each other, so all of a thread's global loads are issued before the first use.
+template <int IN_MODE, int GAUSS_, int TW, int TH, int NT, int D>
+__global__ __launch_bounds__(NT) void k_flow_iter2_w3(RcIterArgs a) {
+    constexpr int MW = TW + 4, MH = TH + 4, MP = MW | 1, PLANE = MH * MP;
     constexpr int NIT = 3, NGRP = (MH + NIT - 1) / NIT;       // a thread owns NIT vertically adjacent pixels
-    static_assert(MW * NGRP <= RC_W3_THREADS, "tile does not fit the block");
+    constexpr int WW = MW + 2 * D, WH = MH + 2 * D, WN = WW * WH, NWL = (WN + NT - 1) / NT;
+    static_assert(MW * NGRP <= NT, "tile does not fit the block");
     extern __shared__ __align__(16) float smf[];
-    float* Ms = smf;                    // [5][MH][MP]: M0 (halo 2), later M1 (halo 1) in place
+    constexpr int WNP = (WN + 63) & ~63;    // whole waves of LDS-DMA
+    float4* LA = (float4*)smf;              // [WH][WW]  R1 (y, x, yy, xx)
+    float* LB = smf + 4 * WNP;              // [WH][WW]  R1 xy
+    float* Ms = LB + WNP;                   // [5][MH][MP]: M0 (halo 2), later M1 (halo 1) in place
     const int tid = threadIdx.x;
     const int z = blockIdx.y;
     const int t = a.xcd_remap ? rc_xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y) : (int)blockIdx.x;
@@ -580,13 +637,48 @@ __global__ __launch_bounds__(RC_W3_THREADS, 4) void k_flow_iter2_w3(RcIterArgs a
     const float4* __restrict__ RA1 = a.RA + s1;  const float* __restrict__ RB1 = a.RB + s1;
     const float2* __restrict__ fin = a.fin + (size_t)z * a.fin_pair_stride;
     char* fout = a.fout + (size_t)z * a.fout_pair_stride;
+    const int ox = tx0 - 2 - D, oy = ty0 - 2 - D;             // window origin (image coordinates)
+#ifdef RC_STAMPS   // diagnostic build only (make STAMPS=1; scripts/exp_stamps.py)
+    const bool stamp = a.stamps && tid == 0 && (blockIdx.x % 61) == 0 && z == 0;
+    long long* st = a.stamps ? a.stamps + (size_t)(blockIdx.x / 61) * 8 : nullptr;
+#define RC_STAMP(i) if (stamp) st[i] = __builtin_amdgcn_s_memtime()
+#else
+#define RC_STAMP(i)
+#endif
+    RC_STAMP(0);
 
     const bool owner = tid < MW * NGRP;
     const int lxo = owner ? tid % MW : 0, ly0 = owner ? (tid / MW) * NIT : 0;
     const int gxo = rc_clampi(tx0 - 2 + lxo, 0, w - 1);
     const int lxc = gxo - (tx0 - 2);          // LDS column of the pixel this column replicates
 #define RC_GY(q) rc_clampi(ty0 - 2 + min(ly0 + (q), MH - 1), 0, h - 1)
-    // ---- flow_in
+
+    // ---- every global load of the block, issued together -------------------------------
+    // The R1 window goes straight to LDS (global_load_lds: per-lane source address, LDS
+    // destination = wave-uniform base + lane * size), so it costs no VGPRs and no ds_write.
+    {
+        const int wave_base = tid & ~63;
+#pragma unroll
+        for (int q = 0; q < NWL; q++) {
+            int idx = tid + q * NT;
+            int wy = idx / WW, wx = idx - wy * WW;
+            int gx = ox + wx, gy = oy + wy;
+            bool ok = idx < WN && (unsigned)gx < (unsigned)w && (unsigned)gy < (unsigned)h;
+            size_t p = ok ? (size_t)gy * w + gx : 0;      // out-of-image texels are never read
+            if (q * NT + wave_base < WN) {                // wave-uniform: whole waves past the window skip
+                rc_glds16(RA1 + p, LA + (q * NT + wave_base));
+                rc_glds4(RB1 + p, LB + (q * NT + wave_base));
+            }
+        }
+    }
+    float4 A0[NIT];
+    float B0[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; q++) {
+        size_t p0 = (size_t)RC_GY(q) * w + gxo;
+        A0[q] = RA0[p0];
+        B0[q] = RB0[p0];
+    }
     float dx[NIT], dy[NIT];
     if constexpr (IN_MODE == 0) {
 #pragma unroll
@@ -619,19 +711,16 @@ __global__ __launch_bounds__(RC_W3_THREADS, 4) void k_flow_iter2_w3(RcIterArgs a
             dy[q] = (r0y * b0 + r1y * b1) * a.up_mul;
         }
     }
-    // ---- iteration 1 matrices: R0 (kept in registers for iteration 2) + gathers
-    float4 A0[NIT];
-    float B0[NIT];
+    RC_STAMP(1);
+    __syncthreads();      // (the compiler drains the pending LDS-DMA with vmcnt(0) here)
+    RC_STAMP(2);
+
+    // ---- iteration 1 matrices (R0 stays in registers for iteration 2)
     {
         RcGather g[NIT];
 #pragma unroll
-        for (int q = 0; q < NIT; q++) {
-            const int gy = RC_GY(q);
-            size_t p0 = (size_t)gy * w + gxo;
-            A0[q] = RA0[p0];
-            B0[q] = RB0[p0];
-            rc_gather_issue(g[q], RA1, RB1, gxo, gy, dx[q], dy[q], w, h);
-        }
+        for (int q = 0; q < NIT; q++)
+            rc_gather_window<WW, WH>(g[q], LA, LB, ox, oy, RA1, RB1, gxo, RC_GY(q), dx[q], dy[q], w, h);
 #pragma unroll
         for (int q = 0; q < NIT; q++) {
             RcM5 v = rc_matrices_reg(A0[q], B0[q], g[q], dx[q], dy[q], gxo, RC_GY(q), w, h);
@@ -642,6 +731,11 @@ __global__ __launch_bounds__(RC_W3_THREADS, 4) void k_flow_iter2_w3(RcIterArgs a
         }
     }
     __syncthreads();
+    RC_STAMP(3);
+    if (a.ablate & 1) {              // ablation: stage A only
+        if (Ms[tid] == 12345.678f) *(float*)fout = 1.f;
+        return;
+    }
     // ---- flow1 at tile + 1 halo (the pixels this thread already owns), then its gathers.
     // The flow of a halo position outside the image is the flow of the pixel it replicates,
     // so the window is centred on that pixel's own LDS position.
@@ -654,12 +748,13 @@ __global__ __launch_bounds__(RC_W3_THREADS, 4) void k_flow_iter2_w3(RcIterArgs a
             float2 f1 = rc_window3_solve<GAUSS_>(Ms, PLANE, MP, gy - (ty0 - 2), lxc, a.win);
             dx[q] = f1.x;
             dy[q] = f1.y;
-            rc_gather_issue(g[q], RA1, RB1, gxo, gy, dx[q], dy[q], w, h);
+            rc_gather_window<WW, WH>(g[q], LA, LB, ox, oy, RA1, RB1, gxo, gy, dx[q], dy[q], w, h);
         }
 #pragma unroll
         for (int q = 0; q < NIT; q++)
             m1[q] = rc_matrices_reg(A0[q], B0[q], g[q], dx[q], dy[q], gxo, RC_GY(q), w, h);
     }
+    RC_STAMP(4);
     __syncthreads();      // every thread is done reading M0
 #pragma unroll
     for (int q = 0; q < NIT; q++) {
@@ -672,27 +767,40 @@ __global__ __launch_bounds__(RC_W3_THREADS, 4) void k_flow_iter2_w3(RcIterArgs a
     }
 #undef RC_GY
     __syncthreads();
+    RC_STAMP(5);
+    if (a.ablate & 4) {              // ablation: no final window/solve/store
+        if (Ms[tid] == 12345.678f) *(float*)fout = 1.f;
+        return;
+    }
     // ---- flow2 on the tile
-    constexpr int RPT = TH / (RC_W3_THREADS / TW);
+    constexpr int RPT = TH / (NT / TW);
     const int lx = tid % TW, r0 = (tid / TW) * RPT;
-    const int ox = tx0 + lx;
-    if (ox < w) {
+    const int oxp = tx0 + lx;
+    if (oxp < w) {
 #pragma unroll
         for (int r = 0; r < RPT; r++) {
-            int oy = ty0 + r0 + r;
-            if (oy < h)
-                *(float2*)(fout + (size_t)oy * a.fout_step + (size_t)ox * 8) =
+            int oyp = ty0 + r0 + r;
+            if (oyp < h)
+                *(float2*)(fout + (size_t)oyp * a.fout_step + (size_t)oxp * 8) =
                     rc_window3_solve<GAUSS_>(Ms, PLANE, MP, r0 + r + 2, lx + 2, a.win);
         }
     }
+    RC_STAMP(6);
+#undef RC_STAMP
+}
+
+template <int IN_MODE, int G, int TW, int TH, int NT, int D>
+static void launch_w3x2_t(RcIterArgs a, int pairs, hipStream_t s) {
+    a.tw = TW; a.th = TH;
+    a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
+    constexpr int WN = (TW + 4 + 2 * D) * (TH + 4 + 2 * D), WNP = (WN + 63) & ~63;
+    size_t lds = sizeof(float) * (5 * WNP + 5 * (TH + 4) * ((TW + 4) | 1));
+    hipLaunchKernelGGL((k_flow_iter2_w3<IN_MODE, G, TW, TH, NT, D>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(NT), lds, s, a);
 }
 
 template <int IN_MODE, int G>
 static void launch_w3x2(RcIterArgs a, int pairs, hipStream_t s) {
-    a.tw = 64; a.th = 16;
-    a.tiles_x = (a.w + 63) / 64; a.tiles_y = (a.h + 15) / 16;
-    size_t lds = sizeof(float) * 5 * 20 * 69;
-    hipLaunchKernelGGL((k_flow_iter2_w3<IN_MODE, G>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(RC_W3_THREADS), lds, s, a);
+    launch_w3x2_t<IN_MODE, G, 32, 16, 256, 4>(a, pairs, s);
 }
 
 int rc_flow_iter_can_fuse2(const RcIterArgs& a) { return a.win.m == 1 && a.solve; }

@@ -40,6 +40,7 @@ struct RcPolyK {
 struct RcWindow {
     float k[RC_MAX_WIN_M + 1];
     double box_scale;
+    double box_eps;           // 1e-3 / box_scale^2: regulariser for unscaled window sums
     int m;
     int gaussian;
 };
@@ -94,6 +95,7 @@ struct RcIterArgs {
     int solve;                // 0: write flow_in (iterations == 0), 1: normal
     int xcd_remap;            // XCD-aware tile order (speed only)
     int ablate;               // timing-only ablation bits (0 in production)
+    long long* stamps;        // diagnostic s_memtime stamps (null in production)
     RcWindow win;
 };
 

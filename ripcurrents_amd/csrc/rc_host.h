@@ -62,6 +62,7 @@ struct rc_ctx {
     int fuse_iters = 1;
     int xcd_remap = 1;
     int ablate = 0;
+    void* stamps = nullptr;
     int prof_on = 0;
     std::vector<RcProfRec> prof_pending;
     std::vector<hipEvent_t> ev_pool;

@@ -215,6 +215,13 @@ extern "C" int rcflow_use_own_stream(rc_ctx* ctx, int stream) {
     return RC_OK;
 }
 
+extern "C" int rcflow_debug_read_stamps(rc_ctx* ctx, long long* out, int n) {
+    if (!ctx || !ctx->stamps || !out || n > 8 * 4096) return RC_EINVAL;
+    RC_HIP(hipDeviceSynchronize());
+    RC_HIP(hipMemcpy(out, ctx->stamps, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return RC_OK;
+}
+
 extern "C" int rcflow_set_option(rc_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return RC_EINVAL;
     if (!strcmp(name, "chunk")) {
@@ -228,6 +235,15 @@ extern "C" int rcflow_set_option(rc_ctx* ctx, const char* name, int value) {
         ctx->xcd_remap = value ? 1 : 0;
     } else if (!strcmp(name, "ablate")) {
         ctx->ablate = value;
+    } else if (!strcmp(name, "stamps")) {
+        // diagnostic: value != 0 allocates a stamp buffer that the scale-0 flow kernel fills
+        if (value && !ctx->stamps) {
+            if (hipMalloc(&ctx->stamps, 8 * 8 * 4096) != hipSuccess) return RC_ENOMEM;
+            (void)hipMemset(ctx->stamps, 0, 8 * 8 * 4096);
+        } else if (!value && ctx->stamps) {
+            (void)hipFree(ctx->stamps);
+            ctx->stamps = nullptr;
+        }
     } else {
         rc_set_error("unknown option %s", name);
         return RC_EINVAL;
@@ -386,6 +402,7 @@ static void host_window(int winsize, int flags, RcWindow& win) {
     win.m = m;
     win.gaussian = (flags & RC_FARNEBACK_GAUSSIAN) ? 1 : 0;
     win.box_scale = 1. / ((double)winsize * winsize);
+    win.box_eps = 1e-3 / (win.box_scale * win.box_scale);
     double sigma = m * 0.3, s = 1;
     win.k[0] = (float)s;
     for (int i = 1; i <= m; i++) {
@@ -535,6 +552,7 @@ static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_
         a.win = pl.win;
         a.xcd_remap = ctx->xcd_remap;
         a.ablate = ctx->ablate;
+        a.stamps = (k == 0) ? (long long*)ctx->stamps : nullptr;
         const float2* cur_in = nullptr;
         int passes = iters > 0 ? iters : 1;
         int nout = 0;   // intermediate buffers written so far at this scale (ping-pong index)
