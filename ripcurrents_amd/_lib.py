@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librcflow.so")
+# RCFLOW_LIB selects another build of the same library (e.g. the diagnostic stamps build)
+LIB_PATH = os.environ.get("RCFLOW_LIB") or os.path.join(_HERE, "librcflow.so")
 
 RC_OK = 0
 RC_FARNEBACK_GAUSSIAN = 256

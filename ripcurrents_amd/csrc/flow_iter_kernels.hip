@@ -514,7 +514,7 @@ __device__ __forceinline__ void rc_gather_issue(RcGather& g, const float4* __res
 }
 
 __device__ __forceinline__ RcM5 rc_matrices_reg(const float4 A0, const float B0, const RcGather& g, float dx,
-                                                float dy, int X, int Y, int w, int h) {
+                                                float dy, int X, int Y, int w, int h, bool BORDER = true) {
     float fx = g.fx, fy = g.fy;
     float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy);
     float a10 = (1.f - fx) * fy, a11 = fx * fy;
@@ -536,7 +536,7 @@ __device__ __forceinline__ RcM5 rc_matrices_reg(const float4 A0, const float B0,
     r3 = (A0.y - r3) * 0.5f;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
-    if ((unsigned)(X - 5) >= (unsigned)(w - 10) || (unsigned)(Y - 5) >= (unsigned)(h - 10)) {
+    if (BORDER && ((unsigned)(X - 5) >= (unsigned)(w - 10) || (unsigned)(Y - 5) >= (unsigned)(h - 10))) {
         float bl = X < 5 ? (X < 2 ? 0.14f : 0.4472f) : 1.f;
         int rx = w - X - 1;
         float br = X >= w - 5 ? (rx < 2 ? 0.14f : 0.4472f) : 1.f;
@@ -651,7 +651,13 @@ __global__ __launch_bounds__(NT) void k_flow_iter2_w3(RcIterArgs a) {
     const int lxo = owner ? tid % MW : 0, ly0 = owner ? (tid / MW) * NIT : 0;
     const int gxo = rc_clampi(tx0 - 2 + lxo, 0, w - 1);
     const int lxc = gxo - (tx0 - 2);          // LDS column of the pixel this column replicates
-#define RC_GY(q) rc_clampi(ty0 - 2 + min(ly0 + (q), MH - 1), 0, h - 1)
+    int gys[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; q++) gys[q] = rc_clampi(ty0 - 2 + min(ly0 + q, MH - 1), 0, h - 1);
+#define RC_GY(q) gys[q]
+    // blocks whose tile + halo stays 5 px away from every image border skip the border-scale
+    // table and the replicate-padding special cases (block-uniform branch)
+    const bool interior = tx0 - 2 >= 5 && tx0 + TW + 2 <= w - 5 && ty0 - 2 >= 5 && ty0 + TH + 2 <= h - 5;
 
     // ---- every global load of the block, issued together -------------------------------
     // The R1 window goes straight to LDS (global_load_lds: per-lane source address, LDS
@@ -723,7 +729,7 @@ __global__ __launch_bounds__(NT) void k_flow_iter2_w3(RcIterArgs a) {
             rc_gather_window<WW, WH>(g[q], LA, LB, ox, oy, RA1, RB1, gxo, RC_GY(q), dx[q], dy[q], w, h);
 #pragma unroll
         for (int q = 0; q < NIT; q++) {
-            RcM5 v = rc_matrices_reg(A0[q], B0[q], g[q], dx[q], dy[q], gxo, RC_GY(q), w, h);
+            RcM5 v = rc_matrices_reg(A0[q], B0[q], g[q], dx[q], dy[q], gxo, RC_GY(q), w, h, !interior);
             if (owner && ly0 + q < MH) {
                 float* mp = Ms + (ly0 + q) * MP + lxo;
                 mp[0] = v.m0; mp[PLANE] = v.m1; mp[2 * PLANE] = v.m2; mp[3 * PLANE] = v.m3; mp[4 * PLANE] = v.m4;
@@ -739,30 +745,75 @@ __global__ __launch_bounds__(NT) void k_flow_iter2_w3(RcIterArgs a) {
     // ---- flow1 at tile + 1 halo (the pixels this thread already owns), then its gathers.
     // The flow of a halo position outside the image is the flow of the pixel it replicates,
     // so the window is centred on that pixel's own LDS position.
+    // Each thread's three pixels are vertically adjacent LDS rows: one 5x3 read per plane.  Rows
+    // and columns of the read block are clamped into the planes; what that distorts are only
+    // positions that are not iteration-2 pixels (outer ring) -- their results are never stored.
     RcM5 m1[NIT];
     {
         RcGather g[NIT];
+        float gs[NIT][5];
+        int rr[NIT + 2];
+#pragma unroll
+        for (int r = 0; r < NIT + 2; r++) rr[r] = rc_clampi(ly0 - 1 + r, 0, MH - 1) * MP;
+        const int c0 = max(lxo - 1, 0), c1 = lxo, c2 = min(lxo + 1, MW - 1);
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const float* mc = Ms + c * PLANE;
+            float col[3][NIT + 2];
+#pragma unroll
+            for (int r = 0; r < NIT + 2; r++) {
+                col[0][r] = mc[rr[r] + c0];
+                col[1][r] = mc[rr[r] + c1];
+                col[2][r] = mc[rr[r] + c2];
+            }
+#pragma unroll
+            for (int q = 0; q < NIT; q++) {
+                float v[3];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    if (GAUSS_) v[j] = col[j][q + 1] * a.win.k[0] + (col[j][q + 2] + col[j][q]) * a.win.k[1];
+                    else v[j] = col[j][q + 1] + (col[j][q + 2] + col[j][q]);
+                }
+                if (GAUSS_) gs[q][c] = v[1] * a.win.k[0] + a.win.k[1] * (v[0] + v[2]);
+                else gs[q][c] = v[1] + (v[2] + v[0]);
+            }
+        }
 #pragma unroll
         for (int q = 0; q < NIT; q++) {
-            const int gy = RC_GY(q);
-            float2 f1 = rc_window3_solve<GAUSS_>(Ms, PLANE, MP, gy - (ty0 - 2), lxc, a.win);
+            float2 f1 = rc_solve3(gs[q], GAUSS_ ? 1e-3 : a.win.box_eps);
             dx[q] = f1.x;
             dy[q] = f1.y;
-            rc_gather_window<WW, WH>(g[q], LA, LB, ox, oy, RA1, RB1, gxo, gy, dx[q], dy[q], w, h);
+            rc_gather_window<WW, WH>(g[q], LA, LB, ox, oy, RA1, RB1, gxo, RC_GY(q), dx[q], dy[q], w, h);
         }
 #pragma unroll
         for (int q = 0; q < NIT; q++)
-            m1[q] = rc_matrices_reg(A0[q], B0[q], g[q], dx[q], dy[q], gxo, RC_GY(q), w, h);
+            m1[q] = rc_matrices_reg(A0[q], B0[q], g[q], dx[q], dy[q], gxo, RC_GY(q), w, h, !interior);
     }
     RC_STAMP(4);
     __syncthreads();      // every thread is done reading M0
+    // M1 is stored for iteration-2 pixels that lie inside the image ...
+    const int px = tx0 - 2 + lxo;
 #pragma unroll
     for (int q = 0; q < NIT; q++) {
-        const int ly = ly0 + q;
-        if (owner && lxo >= 1 && lxo <= MW - 2 && ly >= 1 && ly <= MH - 2) {
+        const int ly = ly0 + q, py = ty0 - 2 + ly;
+        if (owner && lxo >= 1 && lxo <= MW - 2 && ly >= 1 && ly <= MH - 2 && (unsigned)px < (unsigned)w &&
+            (unsigned)py < (unsigned)h) {
             float* mp = Ms + ly * MP + lxo;
             mp[0] = m1[q].m0; mp[PLANE] = m1[q].m1; mp[2 * PLANE] = m1[q].m2; mp[3 * PLANE] = m1[q].m3;
             mp[4 * PLANE] = m1[q].m4;
+        }
+    }
+    if (!interior) {
+        // ... and positions outside the image replicate the border pixel (the window's
+        // replicate border), copied inside LDS.  Block-uniform branch.
+        __syncthreads();
+        for (int idx = tid; idx < (MW - 2) * (MH - 2); idx += NT) {
+            int ly = 1 + idx / (MW - 2), lx = 1 + idx % (MW - 2);
+            int cx = rc_clampi(tx0 - 2 + lx, 0, w - 1) - (tx0 - 2), cy = rc_clampi(ty0 - 2 + ly, 0, h - 1) - (ty0 - 2);
+            if (cx != lx || cy != ly) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) Ms[c * PLANE + ly * MP + lx] = Ms[c * PLANE + cy * MP + cx];
+            }
         }
     }
 #undef RC_GY

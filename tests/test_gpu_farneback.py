@@ -217,7 +217,7 @@ def test_chunk_option_invariance(ctx):
         ctx.set_option("chunk", c)
         b = ctx.farneback_clip(clip, **RC215).cpu().numpy()
         assert np.array_equal(a, b)
-    ctx.set_option("chunk", 8)
+    ctx.set_option("chunk", 16)
 
 
 def test_full_size_1080p_parity(ctx, orc):
