@@ -213,9 +213,11 @@ int rcflow_shear_rate_to_color_dev(rc_ctx* ctx, int stream, const float* d_flow_
 int rcflow_profile_enable(rc_ctx* ctx, int on);
 int rcflow_profile_reset(rc_ctx* ctx);
 /* Resolves pending events and returns per-kernel totals.  names[i] points to a static
- * string "kernel@level"; returns the number of entries written (<= cap). */
+ * string "kernel@level"; returns the number of entries written (<= cap).  alg_bytes = the
+ * launches' compulsory bytes (inputs once + outputs once); model_bytes = SURVEY.md section
+ * 8(d)'s algorithmic bytes of the stages those launches stand for. */
 int rcflow_profile_read(rc_ctx* ctx, int cap, const char** names, int* launches,
-                        double* total_ms, double* alg_bytes);
+                        double* total_ms, double* alg_bytes, double* model_bytes);
 
 #ifdef __cplusplus
 }

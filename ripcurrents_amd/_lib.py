@@ -75,7 +75,7 @@ SIGNATURES = {
     "rcflow_shear_rate_to_color_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz, C.POINTER(_f)],
     "rcflow_profile_enable": [_vp, _i],
     "rcflow_profile_reset": [_vp],
-    "rcflow_profile_read": [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i), C.POINTER(_d), C.POINTER(_d)],
+    "rcflow_profile_read": [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i), C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)],
 }
 
 _LIB = None

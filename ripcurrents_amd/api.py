@@ -414,9 +414,10 @@ class Context:
         launches = (C.c_int * cap)()
         ms = (C.c_double * cap)()
         by = (C.c_double * cap)()
-        n = check(self._lib.rcflow_profile_read(self._h, cap, names, launches, ms, by))
-        return [dict(kernel=names[i].decode(), launches=launches[i], total_ms=ms[i], alg_bytes=by[i])
-                for i in range(n)]
+        mb = (C.c_double * cap)()
+        n = check(self._lib.rcflow_profile_read(self._h, cap, names, launches, ms, by, mb))
+        return [dict(kernel=names[i].decode(), launches=launches[i], total_ms=ms[i], alg_bytes=by[i],
+                     model_bytes=mb[i]) for i in range(n)]
 
 
 def _alias_tensor(ptr, n, dtype, device):

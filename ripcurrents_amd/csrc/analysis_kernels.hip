@@ -99,25 +99,41 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist(const float* flow0, siz
     const int w2 = (w + 1) >> 1;
     const long long total = (long long)w2 * h;
     const long long span = (long long)gridDim.x * RC_BLOCK;
-    // every lane runs the same number of rounds so the ballots see whole waves
+    // every lane runs the same number of rounds so the ballots see whole waves; four loads are in
+    // flight per thread before the first is consumed
     const long long rounds = (total + span - 1) / span;
-    for (long long it = 0; it < rounds; it++) {
-        long long i = it * span + (long long)blockIdx.x * RC_BLOCK + threadIdx.x;
-        int k0 = -1, k1 = -1;
-        if (i < total) {
-            int y = (int)(i / w2), x = (int)(i - (long long)y * w2) * 2;
-            const float2* r = rc_row2(flow, step, y) + x;
-            if (x + 1 < w && (((size_t)r) & 15) == 0) {
-                float4 v = *(const float4*)r;
-                k0 = rc_hist_key(make_float2(v.x, v.y));
-                k1 = rc_hist_key(make_float2(v.z, v.w));
-            } else {
-                k0 = rc_hist_key(r[0]);
-                if (x + 1 < w) k1 = rc_hist_key(r[1]);
+    constexpr int UNR = 4;
+    for (long long it0 = 0; it0 < rounds; it0 += UNR) {
+        float4 v[UNR];
+        int nv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            long long i = (it0 + u) * span + (long long)blockIdx.x * RC_BLOCK + threadIdx.x;
+            nv[u] = 0;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it0 + u < rounds && i < total) {
+                int y = (int)(i / w2), x = (int)(i - (long long)y * w2) * 2;
+                const float2* r = rc_row2(flow, step, y) + x;
+                if (x + 1 < w && (((size_t)r) & 15) == 0) {
+                    v[u] = *(const float4*)r;
+                    nv[u] = 2;
+                } else {
+                    float2 a0 = r[0];
+                    float2 a1 = x + 1 < w ? r[1] : make_float2(0.f, 0.f);
+                    v[u] = make_float4(a0.x, a0.y, a1.x, a1.y);
+                    nv[u] = x + 1 < w ? 2 : 1;
+                }
             }
         }
-        rc_hist_add(lh, k0);
-        rc_hist_add(lh, k1);
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            if (it0 + u < rounds) {      // block-uniform
+                int k0 = nv[u] >= 1 ? rc_hist_key(make_float2(v[u].x, v[u].y)) : -1;
+                int k1 = nv[u] >= 2 ? rc_hist_key(make_float2(v[u].z, v[u].w)) : -1;
+                rc_hist_add(lh, k0);
+                rc_hist_add(lh, k1);
+            }
+        }
     }
     __syncthreads();
     // flush into one of RC_HIST_COPIES partial tables: blocks that share a table queue on

@@ -650,7 +650,6 @@ __global__ __launch_bounds__(NT) void k_flow_iter2_w3(RcIterArgs a) {
     const bool owner = tid < MW * NGRP;
     const int lxo = owner ? tid % MW : 0, ly0 = owner ? (tid / MW) * NIT : 0;
     const int gxo = rc_clampi(tx0 - 2 + lxo, 0, w - 1);
-    const int lxc = gxo - (tx0 - 2);          // LDS column of the pixel this column replicates
     int gys[NIT];
 #pragma unroll
     for (int q = 0; q < NIT; q++) gys[q] = rc_clampi(ty0 - 2 + min(ly0 + q, MH - 1), 0, h - 1);

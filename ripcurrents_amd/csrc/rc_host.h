@@ -50,7 +50,8 @@ struct RcSlot {
 struct RcProfRec {
     int id;
     hipEvent_t e0, e1;
-    double bytes;
+    double bytes;         // compulsory bytes of this launch (inputs once + outputs once)
+    double model_bytes;   // SURVEY.md section 8(d) algorithmic bytes of the stages it covers
 };
 
 struct rc_ctx {
@@ -67,7 +68,7 @@ struct rc_ctx {
     std::vector<RcProfRec> prof_pending;
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> prof_launches;
-    std::vector<double> prof_ms, prof_bytes;
+    std::vector<double> prof_ms, prof_bytes, prof_model_bytes;
 };
 
 enum { RC_K_PYR = 0, RC_K_POLY = 1, RC_K_ITER = 2, RC_K_HIST = 3, RC_K_THRESH = 4, RC_K_CLASSIFY = 5,
@@ -83,8 +84,8 @@ struct RcProfScope {
     hipStream_t s;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int id;
-    double bytes;
-    RcProfScope(rc_ctx* c, hipStream_t st, int kind, int level, double alg_bytes);
+    double bytes, model_bytes;
+    RcProfScope(rc_ctx* c, hipStream_t st, int kind, int level, double alg_bytes, double survey_bytes = -1.);
     ~RcProfScope();
 };
 

@@ -49,8 +49,9 @@ RcSlot* rc_slot(rc_ctx* ctx, int stream) {
 }
 
 // ---------------------------------------------------------------------------- profiling
-RcProfScope::RcProfScope(rc_ctx* c, hipStream_t st, int kind, int level, double alg_bytes)
-    : ctx(c), s(st), id(kind * RC_MAX_LEVELS + level), bytes(alg_bytes) {
+RcProfScope::RcProfScope(rc_ctx* c, hipStream_t st, int kind, int level, double alg_bytes, double survey_bytes)
+    : ctx(c), s(st), id(kind * RC_MAX_LEVELS + level), bytes(alg_bytes),
+      model_bytes(survey_bytes < 0 ? alg_bytes : survey_bytes) {
     if (!ctx->prof_on) return;
     for (int i = 0; i < 2; i++) {
         hipEvent_t e;
@@ -67,7 +68,7 @@ RcProfScope::RcProfScope(rc_ctx* c, hipStream_t st, int kind, int level, double 
 RcProfScope::~RcProfScope() {
     if (!ctx->prof_on || !e0 || !e1) return;
     (void)hipEventRecord(e1, s);
-    ctx->prof_pending.push_back({id, e0, e1, bytes});
+    ctx->prof_pending.push_back({id, e0, e1, bytes, model_bytes});
 }
 
 static const char* kKindNames[RC_K_KINDS] = {"pyr_level", "polyexp", "flow_iter", "polar_hist",
@@ -80,6 +81,7 @@ static void prof_resolve(rc_ctx* ctx) {
     if (ctx->prof_ms.size() != n) {
         ctx->prof_ms.assign(n, 0.);
         ctx->prof_bytes.assign(n, 0.);
+        ctx->prof_model_bytes.assign(n, 0.);
         ctx->prof_launches.assign(n, 0);
     }
     for (auto& r : ctx->prof_pending) {
@@ -88,6 +90,7 @@ static void prof_resolve(rc_ctx* ctx) {
         if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
             ctx->prof_ms[r.id] += ms;
             ctx->prof_bytes[r.id] += r.bytes;
+            ctx->prof_model_bytes[r.id] += r.model_bytes;
             ctx->prof_launches[r.id]++;
         }
         ctx->ev_pool.push_back(r.e0);
@@ -107,11 +110,12 @@ extern "C" int rcflow_profile_reset(rc_ctx* ctx) {
     prof_resolve(ctx);
     ctx->prof_ms.assign(ctx->prof_ms.size(), 0.);
     ctx->prof_bytes.assign(ctx->prof_bytes.size(), 0.);
+    ctx->prof_model_bytes.assign(ctx->prof_model_bytes.size(), 0.);
     ctx->prof_launches.assign(ctx->prof_launches.size(), 0);
     return RC_OK;
 }
 extern "C" int rcflow_profile_read(rc_ctx* ctx, int cap, const char** names, int* launches,
-                                   double* total_ms, double* alg_bytes) {
+                                   double* total_ms, double* alg_bytes, double* model_bytes) {
     if (!ctx) return RC_EINVAL;
     prof_resolve(ctx);
     int n = 0;
@@ -123,6 +127,7 @@ extern "C" int rcflow_profile_read(rc_ctx* ctx, int cap, const char** names, int
         if (launches) launches[n] = ctx->prof_launches[id];
         if (total_ms) total_ms[n] = ctx->prof_ms[id];
         if (alg_bytes) alg_bytes[n] = ctx->prof_bytes[id];
+        if (model_bytes) model_bytes[n] = ctx->prof_model_bytes[id];
         n++;
     }
     return n;
@@ -508,7 +513,8 @@ static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t fr
         if (k == 0) {
             // scale 0: pyramid (3x3 blur, identity resize) fused into the expansion
             qa.src8 = d_src; qa.src8_step = step; qa.src8_frame_stride = frame_stride;
-            RcProfScope ps(ctx, s.cur, RC_K_POLY, k, (double)count * 21. * n);
+            // pyramid (N0 + 4 N0) + expansion (4 N0 + 20 N0) for the two stages fused here
+            RcProfScope ps(ctx, s.cur, RC_K_POLY, k, (double)count * 21. * n, (double)count * 29. * n);
             rc_launch_polyexp(qa, count, s.cur);
             continue;
         }
@@ -584,8 +590,14 @@ static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_
                 cur_in = dst;
             }
             {
+                // SURVEY 8(d) bytes of the stages this launch stands for: the first launch of a scale
+                // carries "init matrices" (8 N_{k+1} + 60 N_k), every iteration but the last 80 N_k
+                // (blur+solve fused with the next matrix update), the last one 28 N_k
+                double model = 0;
+                if (i == 0) model += 60. * n + (coarse ? 8. * cw * ch : 0.);
+                for (int j = i; j < i + fuse; j++) model += (j == passes - 1) ? 28. * n : 80. * n;
                 RcProfScope ps(ctx, s.cur, fuse == 2 ? RC_K_ITER2 : RC_K_ITER, k,
-                               (double)pairs * ((a.solve ? 40. : 0.) * n + in_bytes + 8. * n));
+                               (double)pairs * ((a.solve ? 40. : 0.) * n + in_bytes + 8. * n), (double)pairs * model);
                 if (fuse == 2) rc_launch_flow_iter2(a, pairs, s.cur);
                 else rc_launch_flow_iter(a, pairs, s.cur);
             }

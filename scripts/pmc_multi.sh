@@ -1,11 +1,12 @@
 #!/bin/bash
-# usage: scripts/pmc_multi.sh <tag> <bench args...>   (passes listed in scripts/pmc_passes.txt)
+# usage: scripts/pmc_multi.sh <tag> <bench args...>   (one rocprofv3 --pmc pass per line of scripts/pmc_passes.txt)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  rocprofv3 --pmc $line --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$i -- python3 bench.py "$@" --no-cpu-baseline --no-kernel-events > gpurun_out/pmc_${tag}_$i.log 2>&1 || { echo "pass $i failed: $line"; tail -3 gpurun_out/pmc_${tag}_$i.log; }
+  echo "pass $i: $line"
+  timeout -k 5 120 rocprofv3 --pmc $line --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$i -- python3 bench.py "$@" --no-cpu-baseline --no-kernel-events > gpurun_out/pmc_${tag}_$i.log 2>&1 || { echo "pass $i failed"; tail -2 gpurun_out/pmc_${tag}_$i.log; }
 done < scripts/pmc_passes.txt
 echo done $i passes
