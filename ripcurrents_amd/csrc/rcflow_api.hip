@@ -376,7 +376,7 @@ static int host_prepare_poly(int n, double sigma, int exact_taps, RcPolyK& pk) {
         double t0 = 0, t1 = 0, t2 = 0;
         for (int k = n; k >= 1; k--) {
             t0 += g[k]; t1 += fabs(xg[k]); t2 += xxg[k];
-            if (t0 > 1e-9 * (m0 + g[0]) || t1 > 1e-9 * m1 || t2 > 1e-9 * m2) break;
+            if (t0 > 1e-8 * (m0 + g[0]) || t1 > 1e-8 * m1 || t2 > 1e-8 * m2) break;
             n_thr = k - 1;
         }
         if (n_thr < 1) n_thr = 1;
