@@ -208,6 +208,16 @@ int rcflow_shear_rate_to_color_dev(rc_ctx* ctx, int stream, const float* d_flow_
                                    size_t flow_step, int w, int h, uint8_t* d_hsv,
                                    size_t hsv_step, float* max_frobenius_io); /* :1059-1138 */
 
+/* ------------------------------------------------------------------ SURVEY 8(f) "next" rows
+ * create_edges(outmask) ripcurrents_module.cpp:216-220 (ripcurrents.cpp:477-479): 5x5
+ * MORPH_ELLIPSE dilate followed by the morphological gradient, fused.  Not in place. */
+int rcflow_create_edges_dev(rc_ctx* ctx, int stream, const uint8_t* d_outmask, size_t mask_step,
+                            int w, int h, uint8_t* d_edges, size_t edges_step);
+/* resize(frame, subframe, Size(dw,dh), 0, 0, INTER_LINEAR) + cvtColor(COLOR_BGR2GRAY)
+ * (ripcurrents.cpp:209-210, main.cpp:258-259): 8UC3 BGR frame in, 8UC1 out. */
+int rcflow_resize_bgr_to_gray_dev(rc_ctx* ctx, int stream, const uint8_t* d_bgr, size_t step,
+                                  int sw, int sh, uint8_t* d_gray, size_t gray_step, int dw, int dh);
+
 /* ------------------------------------------------------------------ measurement */
 /* When enabled every kernel launch is bracketed by HIP events on the slot's stream. */
 int rcflow_profile_enable(rc_ctx* ctx, int on);

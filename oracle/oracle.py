@@ -272,3 +272,27 @@ def shear_rate_to_color(flow, max_frobenius, hsv=None):
     lib().orc_shear_rate_to_color(_p(flow), C.c_size_t(flow.strides[0]), w, h,
                                   _p(hsv, C.c_uint8), C.c_size_t(hsv.strides[0]), C.byref(mf))
     return hsv, mf.value
+
+
+def create_edges(mask):
+    mask = np.ascontiguousarray(mask, np.uint8)
+    h, w = mask.shape
+    out = np.zeros_like(mask)
+    lib().orc_create_edges(_p(mask, C.c_uint8), C.c_size_t(mask.strides[0]), w, h, _p(out, C.c_uint8),
+                           C.c_size_t(out.strides[0]))
+    return out
+
+
+def ellipse5():
+    k = np.zeros(25, np.uint8)
+    lib().orc_ellipse5(_p(k, C.c_uint8))
+    return k.reshape(5, 5)
+
+
+def resize_bgr_to_gray(bgr, dw, dh):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    sh, sw = bgr.shape[:2]
+    gray = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_bgr_to_gray(_p(bgr, C.c_uint8), C.c_size_t(bgr.strides[0]), sw, sh, _p(gray, C.c_uint8),
+                                 C.c_size_t(gray.strides[0]), dw, dh)
+    return gray

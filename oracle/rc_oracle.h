@@ -128,6 +128,19 @@ void orc_vector_to_color(const float* flow, size_t flow_step, int w, int h, uint
 void orc_shear_rate_to_color(const float* flow, size_t flow_step, int w, int h,
                              uint8_t* hsv, size_t hsv_step, float* max_frobenius); /* :1059-1138 */
 
+/* ---- section 8(f) "next" rows ---- */
+/* create_edges ripcurrents_module.cpp:216-220 (ripcurrents.cpp:477-479): 5x5 MORPH_ELLIPSE
+ * dilate, then morphological gradient (dilate - erode) of the result.  OpenCV imgproc
+ * morph.cpp semantics: constant border that never wins (0 for dilate, 255 for erode). */
+void orc_create_edges(const uint8_t* mask, size_t mask_step, int w, int h, uint8_t* out,
+                      size_t out_step);
+void orc_ellipse5(uint8_t kernel[25]);   /* getStructuringElement(MORPH_ELLIPSE, Size(5,5)) */
+/* Frame pre-processing ripcurrents.cpp:209-210: resize(frame, subframe, Size(dw,dh), 0, 0,
+ * INTER_LINEAR) on 8UC3 (imgproc resize.cpp fixed-point path, 11-bit coefficients) followed by
+ * cvtColor(COLOR_BGR2GRAY) (color_rgb.cpp: (B*1868 + G*9617 + R*4899 + 8192) >> 14). */
+void orc_resize_bgr_to_gray(const uint8_t* bgr, size_t step, int sw, int sh, uint8_t* gray,
+                            size_t gray_step, int dw, int dh);
+
 #ifdef __cplusplus
 }
 #endif

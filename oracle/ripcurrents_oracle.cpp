@@ -448,4 +448,96 @@ void orc_shear_rate_to_color(const float* flow, size_t flow_step, int w, int h,
     *max_frobenius = max_new;
 }
 
+// ---------------------------------------------------------------- section 8(f) next rows
+// getStructuringElement(MORPH_ELLIPSE, Size(5,5)) -- imgproc morph.cpp
+void orc_ellipse5(uint8_t kernel[25]) {
+    const int ksize = 5, r = 2, c = 2;
+    double inv_r2 = r ? 1. / ((double)r * r) : 0;
+    for (int i = 0; i < ksize; i++) {
+        int j1 = 0, j2 = 0;
+        int dy = i - r;
+        if (std::abs(dy) <= r) {
+            int dx = (int)std::nearbyint(c * std::sqrt((r * r - dy * dy) * inv_r2));   // saturate_cast<int> = cvRound
+            j1 = std::max(c - dx, 0);
+            j2 = std::min(c + dx + 1, ksize);
+        }
+        for (int j = 0; j < ksize; j++) kernel[i * ksize + j] = (j >= j1 && j < j2) ? 1 : 0;
+    }
+}
+
+static void morph5(const uint8_t* src, size_t sstep, int w, int h, uint8_t* dst, size_t dstep, const uint8_t* k,
+                   bool dilate) {
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int v = dilate ? 0 : 255;       // the constant border value that never wins
+            for (int i = 0; i < 5; i++)
+                for (int j = 0; j < 5; j++) {
+                    if (!k[i * 5 + j]) continue;
+                    int yy = y + i - 2, xx = x + j - 2;
+                    if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+                    int s = src[yy * sstep + xx];
+                    v = dilate ? std::max(v, s) : std::min(v, s);
+                }
+            dst[y * dstep + x] = (uint8_t)v;
+        }
+}
+
+// create_edges: dilate(outmask); morphologyEx(outmask, MORPH_GRADIENT) = dilate - erode
+void orc_create_edges(const uint8_t* mask, size_t mask_step, int w, int h, uint8_t* out, size_t out_step) {
+    uint8_t k[25];
+    orc_ellipse5(k);
+    std::vector<uint8_t> m1((size_t)w * h), d((size_t)w * h), e((size_t)w * h);
+    morph5(mask, mask_step, w, h, m1.data(), w, k, true);
+    morph5(m1.data(), w, w, h, d.data(), w, k, true);
+    morph5(m1.data(), w, w, h, e.data(), w, k, false);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) out[y * out_step + x] = (uint8_t)(d[(size_t)y * w + x] - e[(size_t)y * w + x]);
+}
+
+// resize 8UC3 INTER_LINEAR (resize.cpp: 11-bit fixed-point coefficients, HResizeLinear then the
+// uchar VResizeLinear formula) + cvtColor BGR2GRAY (14-bit fixed point)
+void orc_resize_bgr_to_gray(const uint8_t* bgr, size_t step, int sw, int sh, uint8_t* gray, size_t gray_step, int dw,
+                            int dh) {
+    const int cn = 3, COEF = 2048;   // INTER_RESIZE_COEF_SCALE
+    double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    std::vector<int> xofs(dw), yofs(dh);
+    std::vector<short> alpha(2 * dw), beta(2 * dh);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)std::floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        alpha[2 * dx] = (short)std::nearbyint((1.f - fx) * COEF);      // saturate_cast<short>
+        alpha[2 * dx + 1] = (short)std::nearbyint(fx * COEF);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)std::floor(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        beta[2 * dy] = (short)std::nearbyint((1.f - fy) * COEF);
+        beta[2 * dy + 1] = (short)std::nearbyint(fy * COEF);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        int sy0 = std::min(std::max(yofs[dy], 0), sh - 1), sy1 = std::min(std::max(yofs[dy] + 1, 0), sh - 1);
+        const uint8_t* S0 = bgr + (size_t)sy0 * step;
+        const uint8_t* S1 = bgr + (size_t)sy1 * step;
+        int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+        for (int dx = 0; dx < dw; dx++) {
+            int sx = xofs[dx], sx1 = std::min(sx + 1, sw - 1);
+            int a0 = alpha[2 * dx], a1 = alpha[2 * dx + 1];
+            int px[3];
+            for (int c = 0; c < cn; c++) {
+                int h0 = S0[sx * cn + c] * a0 + S0[sx1 * cn + c] * a1;
+                int h1 = S1[sx * cn + c] * a0 + S1[sx1 * cn + c] * a1;
+                px[c] = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                px[c] = std::min(std::max(px[c], 0), 255);
+            }
+            gray[(size_t)dy * gray_step + dx] = (uint8_t)((px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + (1 << 13)) >> 14);
+        }
+    }
+}
+
 }  // extern "C"

@@ -401,6 +401,29 @@ class Context:
                                                        self._ptr(hsv), hsv.stride(0), C.byref(mf)))
         return hsv, mf.value
 
+    # ------------------------------------------------------------------ SURVEY 8(f) next rows
+    def create_edges(self, outmask, stream=0):
+        """create_edges(outmask) ripcurrents_module.cpp:216-220: returns the edge mask."""
+        m = self._dev(outmask, torch.uint8)
+        if m.stride(1) != 1:
+            m = m.contiguous()
+        h, w = m.shape
+        out = torch.empty((h, w), dtype=torch.uint8, device=self.device)
+        self._bind(stream)
+        check(self._lib.rcflow_create_edges_dev(self._h, stream, self._ptr(m), m.stride(0), w, h, self._ptr(out),
+                                                out.stride(0)))
+        return out
+
+    def resize_bgr_to_gray(self, frame, dw, dh, stream=0):
+        """resize(frame, Size(dw,dh), INTER_LINEAR) + cvtColor(BGR2GRAY) (ripcurrents.cpp:209-210)."""
+        f = self._dev(frame, torch.uint8).contiguous()
+        sh, sw = f.shape[:2]
+        out = torch.empty((dh, dw), dtype=torch.uint8, device=self.device)
+        self._bind(stream)
+        check(self._lib.rcflow_resize_bgr_to_gray_dev(self._h, stream, self._ptr(f), f.stride(0), sw, sh,
+                                                      self._ptr(out), out.stride(0), dw, dh))
+        return out
+
     # ------------------------------------------------------------------ measurement
     def profile_enable(self, on=True):
         check(self._lib.rcflow_profile_enable(self._h, 1 if on else 0))

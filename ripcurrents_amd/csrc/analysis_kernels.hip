@@ -516,6 +516,93 @@ __global__ __launch_bounds__(RC_BLOCK) void k_shear_to_color(const float* flow, 
     if (threadIdx.x == 0) part_max[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
 }
 
+// ============================================================================ section 8(f) next rows
+// create_edges (ripcurrents_module.cpp:216-220, ripcurrents.cpp:477-479): dilate with the
+// 5x5 MORPH_ELLIPSE element, then the morphological gradient (dilate - erode) of that result,
+// fused: a 64x16 tile loads the mask with a 4-pixel halo, forms the first dilation on
+// tile+2 in LDS, then both second-stage operators.  Pixels outside the image never win
+// (OpenCV's default constant border: minimum for dilate, maximum for erode).
+__device__ __forceinline__ bool rc_ellipse5(int i, int j) {   // getStructuringElement(MORPH_ELLIPSE, 5x5)
+    return (i == 0 || i == 4) ? (j == 2) : true;
+}
+
+__global__ __launch_bounds__(RC_BLOCK) void k_create_edges(const uint8_t* mask, size_t mask_step, int w, int h,
+                                                           uint8_t* out, size_t out_step) {
+    constexpr int TW = 64, TH = 16, AW = TW + 8, AH = TH + 8, BW = TW + 4, BH = TH + 4;
+    __shared__ uint8_t A[AH][AW];      // mask, tile + 4
+    __shared__ uint8_t B[BH][BW];      // first dilation, tile + 2
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    for (int idx = threadIdx.x; idx < AW * AH; idx += RC_BLOCK) {
+        int ly = idx / AW, lx = idx - ly * AW;
+        int gx = tx0 - 4 + lx, gy = ty0 - 4 + ly;
+        A[ly][lx] = ((unsigned)gx < (unsigned)w && (unsigned)gy < (unsigned)h) ? mask[(size_t)gy * mask_step + gx] : 0;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < BW * BH; idx += RC_BLOCK) {
+        int ly = idx / BW, lx = idx - ly * BW;
+        int v = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int j = 0; j < 5; j++)
+                if (rc_ellipse5(i, j)) v = max(v, (int)A[ly + i][lx + j]);
+        B[ly][lx] = (uint8_t)v;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TW * TH; idx += RC_BLOCK) {
+        int ly = idx / TW, lx = idx - ly * TW;
+        int gx = tx0 + lx, gy = ty0 + ly;
+        if (gx >= w || gy >= h) continue;
+        int d = 0, e = 255;
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int j = 0; j < 5; j++)
+                if (rc_ellipse5(i, j)) {
+                    int yy = gy + i - 2, xx = gx + j - 2;
+                    if ((unsigned)xx < (unsigned)w && (unsigned)yy < (unsigned)h) {
+                        int v = B[ly + i][lx + j];
+                        d = max(d, v);
+                        e = min(e, v);
+                    }
+                }
+        out[(size_t)gy * out_step + gx] = (uint8_t)(d - e);
+    }
+}
+
+// Frame pre-processing (ripcurrents.cpp:209-210): resize(8UC3, INTER_LINEAR) with resize.cpp's
+// 11-bit fixed-point coefficients, then cvtColor(BGR2GRAY) with its 14-bit ones; one thread
+// per output pixel, integer arithmetic throughout (bit-exact).
+__global__ __launch_bounds__(RC_BLOCK) void k_resize_bgr_to_gray(const uint8_t* bgr, size_t step, int sw, int sh,
+                                                                 uint8_t* gray, size_t gray_step, int dw, int dh,
+                                                                 double scale_x, double scale_y) {
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= sw - 1) { fx = 0.f; sx = sw - 1; }
+    const int sx1 = min(sx + 1, sw - 1);
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= sy;
+    const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+    const int a0 = __float2int_rn((1.f - fx) * 2048.f), a1 = __float2int_rn(fx * 2048.f);
+    const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);
+    const uint8_t* S0 = bgr + (size_t)sy0 * step;
+    const uint8_t* S1 = bgr + (size_t)sy1 * step;
+    int px[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        int h0 = S0[sx * 3 + c] * a0 + S0[sx1 * 3 + c] * a1;
+        int h1 = S1[sx * 3 + c] * a0 + S1[sx1 * 3 + c] * a1;
+        int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        px[c] = min(max(v, 0), 255);
+    }
+    gray[(size_t)dy * gray_step + dx] = (uint8_t)((px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + (1 << 13)) >> 14);
+}
+
 // ============================================================================ host side
 static int grid_for(long long items) {
     long long b = (items + RC_BLOCK - 1) / RC_BLOCK;
@@ -859,5 +946,37 @@ extern "C" int rcflow_shear_rate_to_color_dev(rc_ctx* ctx, int stream, const flo
     float mx = 0.f;
     for (float v : hp) mx = v > mx ? v : mx;
     *max_io = mx;
+    return RC_OK;
+}
+
+// ---------------------------------------------------------------------------- section 8(f) entry points
+extern "C" int rcflow_create_edges_dev(rc_ctx* ctx, int stream, const uint8_t* d_mask, size_t mask_step, int w, int h,
+                                       uint8_t* d_out, size_t out_step) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    if (!d_mask || !d_out || w <= 0 || h <= 0 || mask_step < (size_t)w || out_step < (size_t)w || d_mask == d_out) {
+        rc_set_error("bad mask arguments (in-place is not supported)");
+        return RC_EINVAL;
+    }
+    RC_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_create_edges, dim3((w + 63) / 64, (h + 15) / 16), dim3(RC_BLOCK), 0, s->cur, d_mask, mask_step,
+                       w, h, d_out, out_step);
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+extern "C" int rcflow_resize_bgr_to_gray_dev(rc_ctx* ctx, int stream, const uint8_t* d_bgr, size_t step, int sw, int sh,
+                                             uint8_t* d_gray, size_t gray_step, int dw, int dh) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    if (!d_bgr || !d_gray || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || step < (size_t)sw * 3 || gray_step < (size_t)dw) {
+        rc_set_error("bad frame arguments");
+        return RC_EINVAL;
+    }
+    RC_HIP(hipSetDevice(ctx->device));
+    double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    hipLaunchKernelGGL(k_resize_bgr_to_gray, dim3((dw + 63) / 64, (dh + 3) / 4), dim3(RC_BLOCK), 0, s->cur, d_bgr, step,
+                       sw, sh, d_gray, gray_step, dw, dh, scale_x, scale_y);
+    RC_HIP(hipGetLastError());
     return RC_OK;
 }

@@ -284,3 +284,26 @@ def test_frame_loop_like_reference(ctx, orc):
         assert np.array_equal(outs["outmask"].cpu().numpy(), mask)
     gpt, gdist = ctx.streamline_field_state(w, h)
     assert np.array_equal(gpt, pt) and np.array_equal(gdist, dist)
+
+
+def test_create_edges_exact(ctx, orc):
+    """5x5 ellipse dilate + morphological gradient on outmask (integer, exact)."""
+    rng = np.random.RandomState(5)
+    for (w, h) in ((320, 240), (333, 71), (64, 16), (7, 5)):
+        m = (rng.rand(h, w) > 0.97).astype(np.uint8) * 255
+        m[: h // 3, : w // 4] = 255                      # a blob touching the border
+        m[h // 2, :] = rng.randint(0, 256, w)            # arbitrary grey values, not only 0/255
+        got = ctx.create_edges(m).cpu().numpy()
+        assert np.array_equal(got, orc.create_edges(m)), (w, h)
+    assert np.array_equal(orc.ellipse5(), np.uint8([[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1],
+                                                     [0, 0, 1, 0, 0]]))
+
+
+def test_resize_bgr_to_gray_exact(ctx, orc):
+    """resize INTER_LINEAR (fixed point) + BGR2GRAY on device (integer, exact)."""
+    rng = np.random.RandomState(6)
+    for (sw, sh, dw, dh) in ((1280, 720, 640, 480), (641, 479, 640, 480), (320, 240, 640, 480), (640, 480, 640, 480),
+                             (97, 33, 31, 64)):
+        f = rng.randint(0, 256, (sh, sw, 3)).astype(np.uint8)
+        got = ctx.resize_bgr_to_gray(f, dw, dh).cpu().numpy()
+        assert np.array_equal(got, orc.resize_bgr_to_gray(f, dw, dh)), (sw, sh, dw, dh)
