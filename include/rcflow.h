@@ -114,6 +114,17 @@ int rcflow_farneback_clip_dev(rc_ctx* ctx, int stream, const uint8_t* d_frames,
                               size_t frame_stride, size_t step, int nframes, int w, int h,
                               float* d_flows_xy, size_t flow_frame_stride, size_t flow_step,
                               const rc_farneback_params* p);
+/* Lockstep batch of `nstreams` independent video streams (BASELINE config 5): frame t of every
+ * stream arrives together as d_frames[nstreams][h][w]; the slot keeps every stream's previous
+ * expansion, so each call is one pyramid + expansion + flow per stream, all streams in the same
+ * launches.  The first call after rcflow_batch_reset primes the state and returns 1.  With
+ * use_graph != 0 the launch sequence is captured into a hipGraph the second time the same
+ * buffers are seen and replayed from then on (two graphs, one per ring parity). */
+int rcflow_push_batch_dev(rc_ctx* ctx, int stream, const uint8_t* d_frames, size_t frame_stride,
+                          size_t step, int nstreams, int w, int h, float* d_flows_xy,
+                          size_t flow_frame_stride, size_t flow_step,
+                          const rc_farneback_params* p, int use_graph);
+int rcflow_batch_reset(rc_ctx* ctx, int stream);
 /* Level geometry actually used (levels cropped at min_size 32, cvRound sizes).
  * Returns the cropped `levels`; scales are k = 0..levels. */
 int rcflow_level_geometry(int w, int h, double pyr_scale, int levels, int k, int* wk, int* hk);

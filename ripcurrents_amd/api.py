@@ -185,6 +185,23 @@ class Context:
             self._ptr(flows), flows.stride(0) * 4, flows.stride(1) * 4, C.byref(p)))
         return flows
 
+    def push_batch(self, frames, flows=None, use_graph=True, stream=0, **kw):
+        """Lockstep batch of streams: frames [S,H,W] uint8 -> flows [S,H,W,2] (None on the priming call)."""
+        frames = self._dev(frames, torch.uint8)
+        S, h, w = frames.shape
+        p = _params(kw.get("pyr_scale", 0.5), kw.get("levels", 2), kw.get("winsize", 3), kw.get("iterations", 2),
+                    kw.get("poly_n", 15), kw.get("poly_sigma", 1.2), kw.get("flags", 0))
+        if flows is None:
+            flows = torch.empty((S, h, w, 2), dtype=torch.float32, device=frames.device)
+        self._bind(stream)
+        rc = check(self._lib.rcflow_push_batch_dev(self._h, stream, self._ptr(frames), frames.stride(0), frames.stride(1),
+                                                   S, w, h, self._ptr(flows), flows.stride(0) * 4, flows.stride(1) * 4,
+                                                   C.byref(p), 1 if use_graph else 0))
+        return None if rc == 1 else flows
+
+    def batch_reset(self, stream=0):
+        check(self._lib.rcflow_batch_reset(self._h, stream))
+
     def level_geometry(self, w, h, pyr_scale, levels, k):
         wk, hk = C.c_int(), C.c_int()
         L = check(self._lib.rcflow_level_geometry(w, h, pyr_scale, levels, k, C.byref(wk), C.byref(hk)))

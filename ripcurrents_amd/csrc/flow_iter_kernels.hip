@@ -141,8 +141,8 @@ __global__ __launch_bounds__(RC_BLOCK) void k_flow_iter(RcIterArgs a) {
     const int MW = tw + 2 * m, MH = th + 2 * m, MP = MW | 1;
     float* Ms = smf;                    // [5][MH][MP]
 
-    const size_t s0 = (size_t)((a.slot0 + z) % a.nslots) * a.R_slot_stride;
-    const size_t s1 = (size_t)((a.slot1 + z) % a.nslots) * a.R_slot_stride;
+    const size_t s0 = (size_t)((a.slot0 + z * a.zstep) % a.nslots) * a.R_slot_stride;
+    const size_t s1 = (size_t)((a.slot1 + z * a.zstep) % a.nslots) * a.R_slot_stride;
     const float4* RA0 = a.RA + s0;  const float* RB0 = a.RB + s0;
     const float4* RA1 = a.RA + s1;  const float* RB1 = a.RB + s1;
     const float2* fin = a.fin ? a.fin + (size_t)z * a.fin_pair_stride : nullptr;
@@ -308,8 +308,8 @@ __global__ __launch_bounds__(RC_W3_THREADS) void k_flow_iter_w3(RcIterArgs a) {
     const int t = a.xcd_remap ? rc_xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y) : (int)blockIdx.x;
     const int tx0 = (t % a.tiles_x) * TW, ty0 = (t / a.tiles_x) * TH;
     const int w = a.w, h = a.h;
-    const size_t s0 = (size_t)((a.slot0 + z) % a.nslots) * a.R_slot_stride;
-    const size_t s1 = (size_t)((a.slot1 + z) % a.nslots) * a.R_slot_stride;
+    const size_t s0 = (size_t)((a.slot0 + z * a.zstep) % a.nslots) * a.R_slot_stride;
+    const size_t s1 = (size_t)((a.slot1 + z * a.zstep) % a.nslots) * a.R_slot_stride;
     const float4* __restrict__ RA0 = a.RA + s0;  const float* __restrict__ RB0 = a.RB + s0;
     const float4* __restrict__ RA1 = a.RA + s1;  const float* __restrict__ RB1 = a.RB + s1;
     const float2* __restrict__ fin = a.fin + (size_t)z * a.fin_pair_stride;
@@ -631,8 +631,8 @@ __global__ __launch_bounds__(NT) void k_flow_iter2_w3(RcIterArgs a) {
     const int t = a.xcd_remap ? rc_xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y) : (int)blockIdx.x;
     const int tx0 = (t % a.tiles_x) * TW, ty0 = (t / a.tiles_x) * TH;
     const int w = a.w, h = a.h;
-    const size_t s0 = (size_t)((a.slot0 + z) % a.nslots) * a.R_slot_stride;
-    const size_t s1 = (size_t)((a.slot1 + z) % a.nslots) * a.R_slot_stride;
+    const size_t s0 = (size_t)((a.slot0 + z * a.zstep) % a.nslots) * a.R_slot_stride;
+    const size_t s1 = (size_t)((a.slot1 + z * a.zstep) % a.nslots) * a.R_slot_stride;
     const float4* __restrict__ RA0 = a.RA + s0;  const float* __restrict__ RB0 = a.RB + s0;
     const float4* __restrict__ RA1 = a.RA + s1;  const float* __restrict__ RB1 = a.RB + s1;
     const float2* __restrict__ fin = a.fin + (size_t)z * a.fin_pair_stride;

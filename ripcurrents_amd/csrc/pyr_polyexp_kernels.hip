@@ -103,7 +103,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_pyr_level(RcPyrArgs a) {
     }
     __syncthreads();
 
-    const int slot = (a.dslot0 + z) % a.nslots;
+    const int slot = (a.dslot0 + z * a.zstep) % a.nslots;
     float* dst = a.dst + (size_t)slot * a.dst_slot_stride;
     for (int ly = wv; ly < ny; ly += RC_BLOCK / 64) {
         const int i0 = ys[2 * ly] - reg_y0, i1 = ys[2 * ly + 1] - reg_y0;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_pyr_direct(RcPyrArgs a) {
     float a0 = 1.f - ax, a1 = ax, w0 = 1.f - ay, w1 = ay;
     float r0 = b00 * a0 + b01 * a1;
     float r1 = b10 * a0 + b11 * a1;
-    const int slot = (a.dslot0 + z) % a.nslots;
+    const int slot = (a.dslot0 + z * a.zstep) % a.nslots;
     a.dst[(size_t)slot * a.dst_slot_stride + (size_t)dy * a.w + dx] = r0 * w0 + r1 * w1;
 }
 
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(RC_POLY_BLOCK) void k_polyexp(RcPolyArgs a) {
     const int z = blockIdx.z;
     const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
     const int w = a.w, h = a.h;
-    const int slot = (a.slot0 + z) % a.nslots;
+    const int slot = (a.slot0 + z * a.zstep) % a.nslots;
     float dc;
 
     if constexpr (U8) {

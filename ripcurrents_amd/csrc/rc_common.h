@@ -52,7 +52,7 @@ struct RcPyrArgs {
     int W0, H0;
     float* dst;               // I_k slot base
     size_t dst_slot_stride;   // floats per slot
-    int dslot0, nslots;       // destination slot of frame z is (dslot0+z)%nslots
+    int dslot0, nslots, zstep; // destination slot of frame z is (dslot0 + z*zstep) % nslots
     int w, h;
     double scale_x, scale_y;
     int ksize;
@@ -68,7 +68,7 @@ struct RcPolyArgs {
     float4* RA;               // (y, x, yy, xx) coefficients
     float* RB;                // xy coefficient
     size_t R_slot_stride;     // elements per slot (pixels)
-    int slot0, nslots;
+    int slot0, nslots, zstep;
     int w, h;
     RcPolyK pk;
 };
@@ -77,7 +77,7 @@ struct RcIterArgs {
     const float4* RA;         // R slot base of this level
     const float* RB;
     size_t R_slot_stride;
-    int slot0, slot1, nslots; // pair z uses slots (slot0+z)%n and (slot1+z)%n
+    int slot0, slot1, nslots, zstep; // pair z uses slots (slot0 + z*zstep) % n and (slot1 + z*zstep) % n
     int w, h;
     // flow in: mode 0 zeros, 1 same-resolution, 2 coarser level (resize * mul)
     int in_mode;

@@ -36,6 +36,12 @@ struct RcAnalysis {
     RcBuf scratch;     // reductions
 };
 
+struct RcBatchKey {
+    const void* frames; size_t frame_stride, step;
+    void* flows; size_t flow_frame_stride, flow_step;
+    void* hip_stream;
+};
+
 struct RcSlot {
     hipStream_t own = nullptr, cur = nullptr;
     RcPlan plan;
@@ -44,6 +50,11 @@ struct RcSlot {
     RcBuf FA[RC_MAX_LEVELS], FB[RC_MAX_LEVELS];
     RcBuf stage_u8, stage_flow, stage_f32[4];
     int primed = 0, cur_slot = 0;
+    // lockstep batch of streams (rcflow_push_batch_dev): parity of the ring, captured graphs
+    int batch_primed = 0, batch_cur = 0;
+    void* batch_exec[2] = {nullptr, nullptr};
+    int batch_eager[2] = {0, 0};
+    RcBatchKey batch_key[2] = {};
     RcAnalysis an;
 };
 
@@ -78,6 +89,7 @@ void rc_set_error(const char* fmt, ...);
 int rc_buf_ensure(RcBuf& b, size_t bytes);
 void rc_buf_free(RcBuf& b);
 RcSlot* rc_slot(rc_ctx* ctx, int stream);
+void rc_batch_graph_drop(RcSlot& s);
 
 struct RcProfScope {
     rc_ctx* ctx;

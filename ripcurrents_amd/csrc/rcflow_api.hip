@@ -178,6 +178,7 @@ static void slot_free(RcSlot& s) {
         rc_buf_free(s.I[k]); rc_buf_free(s.RA[k]); rc_buf_free(s.RB[k]);
         rc_buf_free(s.FA[k]); rc_buf_free(s.FB[k]);
     }
+    rc_batch_graph_drop(s);
     rc_buf_free(s.stage_u8); rc_buf_free(s.stage_flow);
     for (auto& b : s.stage_f32) rc_buf_free(b);
     rc_buf_free(s.an.hist); rc_buf_free(s.an.hist_part); rc_buf_free(s.an.thr); rc_buf_free(s.an.acc);
@@ -450,7 +451,8 @@ static int params_valid(const rc_farneback_params* p) {
     return 1;
 }
 
-static int ensure_plan(rc_ctx* ctx, RcSlot& s, int w, int h, const rc_farneback_params* p, int chunk) {
+static int ensure_plan(rc_ctx* ctx, RcSlot& s, int w, int h, const rc_farneback_params* p, int chunk, int nslots = 0) {
+    if (nslots <= 0) nslots = chunk + 1;
     if (w <= 0 || h <= 0 || !params_valid(p)) {
         rc_set_error("invalid Farneback arguments (w=%d h=%d)", w, h);
         return RC_EINVAL;
@@ -461,11 +463,12 @@ static int ensure_plan(rc_ctx* ctx, RcSlot& s, int w, int h, const rc_farneback_
     }
     RcPlan& pl = s.plan;
     if (pl.valid && pl.w == w && pl.h == h && !memcmp(&pl.prm, p, sizeof(*p)) && pl.chunk == chunk &&
-        pl.exact_taps == ctx->exact_taps)
+        pl.nslots == nslots && pl.exact_taps == ctx->exact_taps)
         return RC_OK;
+    rc_batch_graph_drop(s);
     RC_HIP(hipStreamSynchronize(s.cur));
     pl.valid = false;
-    pl.w = w; pl.h = h; pl.prm = *p; pl.chunk = chunk; pl.nslots = chunk + 1;
+    pl.w = w; pl.h = h; pl.prm = *p; pl.chunk = chunk; pl.nslots = nslots;
     pl.exact_taps = ctx->exact_taps;
     int L = crop_levels(w, h, p->pyr_scale, p->levels);
     pl.nlev = L + 1;
@@ -494,6 +497,7 @@ static int ensure_plan(rc_ctx* ctx, RcSlot& s, int w, int h, const rc_farneback_
         if ((rc = rc_buf_ensure(s.FB[k], n * chunk * sizeof(float2)))) return rc;
     }
     s.primed = 0;
+    s.batch_primed = 0;
     pl.valid = true;
     return RC_OK;
 }
@@ -501,7 +505,7 @@ static int ensure_plan(rc_ctx* ctx, RcSlot& s, int w, int h, const rc_farneback_
 // ---------------------------------------------------------------------------- level driver
 // Pyramid + polynomial expansion of `count` frames into R slots dslot0.. (A1 + A2).
 static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t frame_stride, size_t step,
-                         int count, int dslot0) {
+                         int count, int dslot0, int zstep = 1) {
     RcPlan& pl = s.plan;
     for (int k = 0; k < pl.nlev; k++) {
         const RcLevel& L = pl.lv[k];
@@ -509,7 +513,7 @@ static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t fr
         RcPolyArgs qa;
         memset(&qa, 0, sizeof(qa));
         qa.RA = (float4*)s.RA[k].p; qa.RB = (float*)s.RB[k].p; qa.R_slot_stride = n;
-        qa.slot0 = dslot0; qa.nslots = pl.nslots; qa.w = L.w; qa.h = L.h; qa.pk = pl.pk;
+        qa.slot0 = dslot0; qa.nslots = pl.nslots; qa.zstep = zstep; qa.w = L.w; qa.h = L.h; qa.pk = pl.pk;
         if (k == 0) {
             // scale 0: pyramid (3x3 blur, identity resize) fused into the expansion
             qa.src8 = d_src; qa.src8_step = step; qa.src8_frame_stride = frame_stride;
@@ -522,7 +526,7 @@ static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t fr
         pa.src = d_src; pa.src_step = step; pa.src_frame_stride = frame_stride;
         pa.W0 = pl.w; pa.H0 = pl.h;
         pa.dst = (float*)s.I[k].p; pa.dst_slot_stride = n;
-        pa.dslot0 = dslot0; pa.nslots = pl.nslots;
+        pa.dslot0 = dslot0; pa.nslots = pl.nslots; pa.zstep = zstep;
         pa.w = L.w; pa.h = L.h; pa.scale_x = L.scale_x; pa.scale_y = L.scale_y;
         pa.ksize = L.ksize; pa.kern = (const float*)s.kern.p + pl.kern_off[k];
         pa.tw = L.pyr_tw; pa.th = L.pyr_th; pa.reg_wp = L.pyr_reg_w; pa.reg_hmax = L.pyr_reg_h;
@@ -542,7 +546,7 @@ static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t fr
 
 // Coarse-to-fine flow for `pairs` frame pairs whose expansions sit in slots slot0+z, slot0+z+1.
 static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_out, size_t out_pair_stride,
-                         size_t out_step) {
+                         size_t out_step, int slot1 = -1, int zstep = 1) {
     RcPlan& pl = s.plan;
     const int iters = pl.prm.iterations;
     const float2* coarse = nullptr;
@@ -553,7 +557,7 @@ static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_
         RcIterArgs a;
         memset(&a, 0, sizeof(a));
         a.RA = (const float4*)s.RA[k].p; a.RB = (const float*)s.RB[k].p; a.R_slot_stride = n;
-        a.slot0 = slot0; a.slot1 = (slot0 + 1) % pl.nslots; a.nslots = pl.nslots;
+        a.slot0 = slot0; a.slot1 = slot1 >= 0 ? slot1 : (slot0 + 1) % pl.nslots; a.nslots = pl.nslots; a.zstep = zstep;
         a.w = L.w; a.h = L.h;
         a.win = pl.win;
         a.xcd_remap = ctx->xcd_remap;
@@ -624,6 +628,7 @@ extern "C" int rcflow_farneback_dev(rc_ctx* ctx, int stream, const uint8_t* d_pr
     int rc = ensure_plan(ctx, *s, w, h, p, ctx->chunk);
     if (rc) return rc;
     s->primed = 0;
+    s->batch_primed = 0;
     if ((rc = expand_frames(ctx, *s, d_prev, 0, prev_step, 1, 0))) return rc;
     if ((rc = expand_frames(ctx, *s, d_next, 0, next_step, 1, 1))) return rc;
     return compute_flows(ctx, *s, 1, 0, d_flow, 0, flow_step);
@@ -675,6 +680,7 @@ extern "C" int rcflow_push_frame_dev(rc_ctx* ctx, int stream, const uint8_t* d_f
     int rc = ensure_plan(ctx, *s, w, h, p, ctx->chunk);
     if (rc) return rc;
     if (!was_valid) s->primed = 0;
+    s->batch_primed = 0;
     if (!s->primed) {
         if ((rc = expand_frames(ctx, *s, d_frame, 0, step, 1, 0))) return rc;
         s->primed = 1;
@@ -704,6 +710,7 @@ extern "C" int rcflow_farneback_clip_dev(rc_ctx* ctx, int stream, const uint8_t*
     int rc = ensure_plan(ctx, *s, w, h, p, ctx->chunk);
     if (rc) return rc;
     s->primed = 0;
+    s->batch_primed = 0;
     const int C = s->plan.chunk, ns = s->plan.nslots;
     int s0 = 0;
     if ((rc = expand_frames(ctx, *s, d_frames, frame_stride, step, 1, 0))) return rc;
@@ -718,6 +725,95 @@ extern "C" int rcflow_farneback_clip_dev(rc_ctx* ctx, int stream, const uint8_t*
         s0 = (s0 + np) % ns;
         t += np;
     }
+    return RC_OK;
+}
+
+// ---------------------------------------------------------------------------- lockstep batch of streams
+void rc_batch_graph_drop(RcSlot& s) {
+    for (int i = 0; i < 2; i++) {
+        if (s.batch_exec[i]) (void)hipGraphExecDestroy((hipGraphExec_t)s.batch_exec[i]);
+        s.batch_exec[i] = nullptr;
+        s.batch_eager[i] = 0;
+    }
+}
+
+static int batch_launches(rc_ctx* ctx, RcSlot& s, const uint8_t* d_frames, size_t frame_stride, size_t step, int S,
+                          float* d_flows, size_t flow_frame_stride, size_t flow_step, int cur) {
+    int rc = expand_frames(ctx, s, d_frames, frame_stride, step, S, cur ^ 1, 2);
+    if (rc) return rc;
+    return compute_flows(ctx, s, S, cur, d_flows, flow_frame_stride, flow_step, cur ^ 1, 2);
+}
+
+extern "C" int rcflow_push_batch_dev(rc_ctx* ctx, int stream, const uint8_t* d_frames, size_t frame_stride, size_t step,
+                                     int nstreams, int w, int h, float* d_flows, size_t flow_frame_stride,
+                                     size_t flow_step, const rc_farneback_params* p, int use_graph) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !d_frames || nstreams < 1 || nstreams > 4096) { if (s) rc_set_error("bad batch arguments"); return RC_EINVAL; }
+    if (step < (size_t)w || (nstreams > 1 && frame_stride < step * (size_t)(h - 1) + w)) {
+        rc_set_error("batch strides smaller than a frame");
+        return RC_EINVAL;
+    }
+    RC_HIP(hipSetDevice(ctx->device));
+    // every stream keeps a ring of two expansions: slot 2*z + parity
+    int rc = ensure_plan(ctx, *s, w, h, p, nstreams, 2 * nstreams);
+    if (rc) return rc;
+    s->primed = 0;
+    if (!s->batch_primed) {
+        rc_batch_graph_drop(*s);
+        if ((rc = expand_frames(ctx, *s, d_frames, frame_stride, step, nstreams, 0, 2))) return rc;
+        s->batch_primed = 1;
+        s->batch_cur = 0;
+        return 1;
+    }
+    if (!d_flows || flow_step < (size_t)w * 8 ||
+        (nstreams > 1 && flow_frame_stride < flow_step * (size_t)(h - 1) + (size_t)w * 8)) {
+        rc_set_error("bad flow batch buffer");
+        return RC_EINVAL;
+    }
+    const int cur = s->batch_cur;
+    RcBatchKey key = {d_frames, frame_stride, step, d_flows, flow_frame_stride, flow_step, (void*)s->cur};
+    const bool graph_ok = use_graph && !ctx->prof_on;
+    if (graph_ok && s->batch_exec[cur] && !memcmp(&key, &s->batch_key[cur], sizeof(key))) {
+        // steady state: replay the captured launch sequence of this parity
+        RC_HIP(hipGraphLaunch((hipGraphExec_t)s->batch_exec[cur], s->cur));
+    } else if (graph_ok && s->batch_eager[cur] && !memcmp(&key, &s->batch_key[cur], sizeof(key))) {
+        // second time with the same buffers: capture while launching
+        // the null stream cannot capture: record on the slot's own stream (capture executes
+        // nothing) and launch the instantiated graph on the caller's stream
+        hipGraph_t graph = nullptr;
+        hipStream_t run_stream = s->cur, cap_stream = s->cur ? s->cur : s->own;
+        RC_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeRelaxed));
+        s->cur = cap_stream;
+        rc = batch_launches(ctx, *s, d_frames, frame_stride, step, nstreams, d_flows, flow_frame_stride, flow_step, cur);
+        s->cur = run_stream;
+        hipError_t e = hipStreamEndCapture(cap_stream, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess || !graph) { rc_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return RC_EHIP; }
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { rc_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e)); return RC_EHIP; }
+        if (s->batch_exec[cur]) (void)hipGraphExecDestroy((hipGraphExec_t)s->batch_exec[cur]);
+        s->batch_exec[cur] = exec;
+        RC_HIP(hipGraphLaunch(exec, s->cur));
+    } else {
+        if (s->batch_exec[cur]) { (void)hipGraphExecDestroy((hipGraphExec_t)s->batch_exec[cur]); s->batch_exec[cur] = nullptr; }
+        if ((rc = batch_launches(ctx, *s, d_frames, frame_stride, step, nstreams, d_flows, flow_frame_stride, flow_step, cur)))
+            return rc;
+        s->batch_key[cur] = key;
+        s->batch_eager[cur] = 1;
+    }
+    s->batch_cur = cur ^ 1;
+    return RC_OK;
+}
+
+extern "C" int rcflow_batch_reset(rc_ctx* ctx, int stream) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    RC_HIP(hipStreamSynchronize(s->cur));
+    rc_batch_graph_drop(*s);
+    s->batch_primed = 0;
+    s->batch_cur = 0;
     return RC_OK;
 }
 
@@ -738,7 +834,7 @@ extern "C" int rcflow_stage_pyr_level_dev(rc_ctx* ctx, int stream, const uint8_t
     RC_HIP(hipStreamSynchronize(s->cur));
     RcPyrArgs pa;
     pa.src = d_img; pa.src_step = step; pa.src_frame_stride = 0; pa.W0 = w; pa.H0 = h;
-    pa.dst = d_out; pa.dst_slot_stride = 0; pa.dslot0 = 0; pa.nslots = 1;
+    pa.dst = d_out; pa.dst_slot_stride = 0; pa.dslot0 = 0; pa.nslots = 1; pa.zstep = 1;
     pa.w = L.w; pa.h = L.h; pa.scale_x = L.scale_x; pa.scale_y = L.scale_y;
     pa.ksize = L.ksize; pa.kern = (const float*)s->stage_f32[0].p;
     pa.tw = L.pyr_tw; pa.th = L.pyr_th; pa.reg_wp = L.pyr_reg_w; pa.reg_hmax = L.pyr_reg_h;
@@ -760,7 +856,7 @@ extern "C" int rcflow_stage_polyexp_dev(rc_ctx* ctx, int stream, const float* d_
     memset(&qa, 0, sizeof(qa));
     qa.I = d_I; qa.I_slot_stride = 0;
     qa.RA = (float4*)s->stage_f32[0].p; qa.RB = (float*)s->stage_f32[1].p; qa.R_slot_stride = 0;
-    qa.slot0 = 0; qa.nslots = 1; qa.w = w; qa.h = h;
+    qa.slot0 = 0; qa.nslots = 1; qa.zstep = 1; qa.w = w; qa.h = h;
     if ((rc = host_prepare_poly(poly_n, poly_sigma, ctx->exact_taps, qa.pk))) return rc;
     rc_launch_polyexp(qa, 1, s->cur);
     rc_launch_unpack_R5(qa.RA, qa.RB, d_R5, (int)n, s->cur);
@@ -788,7 +884,7 @@ extern "C" int rcflow_stage_flow_iter_dev(rc_ctx* ctx, int stream, const float* 
     host_window(winsize, flags, win);
     RcIterArgs a;
     memset(&a, 0, sizeof(a));
-    a.RA = RA; a.RB = RB; a.R_slot_stride = n; a.slot0 = 0; a.slot1 = 1; a.nslots = 2;
+    a.RA = RA; a.RB = RB; a.R_slot_stride = n; a.slot0 = 0; a.slot1 = 1; a.nslots = 2; a.zstep = 1;
     a.w = w; a.h = h;
     a.in_mode = d_flow_in ? 1 : 0; a.fin = (const float2*)d_flow_in; a.fin_pair_stride = n;
     a.fout = (char*)d_flow_out; a.fout_step = (size_t)w * 8; a.fout_pair_stride = n * 8;

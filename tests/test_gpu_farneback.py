@@ -297,3 +297,29 @@ def test_against_committed_golden_fixtures(ctx):
     assert st.histsum == h["histsum"].item() and np.array_equal(st.histsum2d, h["histsum2d"])
     assert st.UPPER == h["UPPER"].item() and np.array_equal(st.UPPER2d, h["UPPER2d"])
     assert np.array_equal(st.prop_above_upper, h["prop_above_upper"], equal_nan=True)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_lockstep_stream_batch_matches_per_stream(ctx, use_graph):
+    """BASELINE config 5 as a parity case: 16 independent streams advanced in lockstep through
+    batched launches (hipGraph replay in steady state) give bit-identical flows to 16 separate
+    two-image calls."""
+    S, T, w, h = 16, 6, 192, 128
+    clips = np.stack([synth.surf_clip(w, h, T, seed=100 + s) for s in range(S)])        # [S,T,h,w]
+    d = torch.as_tensor(clips).cuda()
+    frames = torch.empty((S, h, w), dtype=torch.uint8, device="cuda")                    # fixed staging buffers
+    flows = torch.empty((S, h, w, 2), dtype=torch.float32, device="cuda")
+    ctx.batch_reset()
+    got = []
+    for t in range(T):
+        frames.copy_(d[:, t])
+        r = ctx.push_batch(frames, flows, use_graph=use_graph, **RC215)
+        if r is not None:
+            ctx.sync()
+            got.append(r.cpu().numpy().copy())
+    assert len(got) == T - 1
+    for s in (0, 7, 15):
+        for t in range(T - 1):
+            ref = ctx.calcOpticalFlowFarneback(clips[s, t], clips[s, t + 1], None, **RC215)
+            assert np.array_equal(got[t][s], ref), (s, t)
+    ctx.batch_reset()
