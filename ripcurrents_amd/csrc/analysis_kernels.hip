@@ -64,14 +64,16 @@ __device__ __forceinline__ const float2* rc_row2(const float* base, size_t step,
 // fall into a handful of bins: lanes are grouped by key with ballots and each group
 // costs one LDS atomic (added with the group's population count).
 #define RC_HIST_COPIES 16
+template <int ROUNDS>
 __device__ __forceinline__ void rc_hist_add(int* lh, int key) {
-    // Peel off the two most popular keys of the wave with scalar control flow (ballot masks
-    // in SGPRs, the leader's key by v_readlane): smooth fields put most lanes there.  What
-    // is left takes plain per-lane LDS atomics (distinct keys do not conflict).
+    // Peel off the most popular key(s) of the wave with scalar control flow (ballot masks in
+    // SGPRs, the leader's key by v_readlane): a uniform field would otherwise serialise 64
+    // same-address LDS atomics.  What is left takes plain per-lane LDS atomics (distinct keys
+    // do not conflict); on textured flows more than one round cost more than it saved.
     unsigned long long todo = __ballot(key >= 0);
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int round = 0; round < 2; round++) {
+    for (int round = 0; round < ROUNDS; round++) {
         if (!todo) break;
         int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
         int k = __builtin_amdgcn_readlane(key, leader);
@@ -90,6 +92,7 @@ __device__ __forceinline__ int rc_hist_key(float2 f) {
     return rc_dir_index(rc_fast_atan2_deg(f.y, f.x)) * RC_HIST_BINS + bin;
 }
 
+template <int ROUNDS>
 __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist(const float* flow0, size_t frame_stride, size_t step,
                                                          int w, int h, int* parts) {
     __shared__ int lh[RC_HIST_DIRECTIONS * RC_HIST_BINS];
@@ -130,8 +133,8 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist(const float* flow0, siz
             if (it0 + u < rounds) {      // block-uniform
                 int k0 = nv[u] >= 1 ? rc_hist_key(make_float2(v[u].x, v[u].y)) : -1;
                 int k1 = nv[u] >= 2 ? rc_hist_key(make_float2(v[u].z, v[u].w)) : -1;
-                rc_hist_add(lh, k0);
-                rc_hist_add(lh, k1);
+                rc_hist_add<ROUNDS>(lh, k0);
+                rc_hist_add<ROUNDS>(lh, k1);
             }
         }
     }
@@ -667,10 +670,12 @@ extern "C" int rcflow_histogram_clip_dev(rc_ctx* ctx, int stream, const float* d
         RcProfScope ps(ctx, s->cur, RC_K_HIST, 0, 8. * w * h * count);
         long long per_frame = ((long long)(w + 1) / 2) * h;
         int nb = grid_for(per_frame);
-        int cap = 2048 / count;       // about 8 blocks per CU over the whole launch
+        // many light blocks (measured: 16384 total beat 2048 by 25 %): the partial tables keep
+        // the flush chains short, and one ballot round catches the dominant bin of a wave
+        int cap = 16384 / count;
         if (cap < 8) cap = 8;
         if (nb > cap) nb = cap;
-        hipLaunchKernelGGL(k_polar_hist, dim3(nb, count), dim3(RC_BLOCK), 0, s->cur, d_flows, flow_frame_stride,
+        hipLaunchKernelGGL(k_polar_hist<1>, dim3(nb, count), dim3(RC_BLOCK), 0, s->cur, d_flows, flow_frame_stride,
                            flow_step, w, h, (int*)s->an.hist_part.p);
         hipLaunchKernelGGL(k_hist_fold, dim3((RC_HIST_DIRECTIONS * RC_HIST_BINS + RC_BLOCK - 1) / RC_BLOCK),
                            dim3(RC_BLOCK), 0, s->cur, (int*)s->an.hist_part.p, (int*)s->an.hist.p);

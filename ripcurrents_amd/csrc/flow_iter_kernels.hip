@@ -44,39 +44,47 @@ __device__ __forceinline__ float2 rc_flow_in(const RcIterArgs& a, const float2* 
     return v;
 }
 
-// FarnebackUpdateMatrices for one pixel (operation order of optflow.cpp kept; built with
-// -ffp-contract=off so nothing here fuses).
+// FarnebackUpdateMatrices for one pixel, in two steps so that a thread can have the gathers of
+// several pixels in flight: rc_gather_issue starts the loads, rc_matrices_reg consumes them.
+// Every flow kernel goes through these two functions, so they all produce the same bits.
+// Sums of products are written as fused multiply-adds (one rounding per term, like an
+// FMA-enabled build of the upstream C++); the rest keeps optflow.cpp's operation order.
 struct RcM5 { float m0, m1, m2, m3, m4; };
 
-__device__ __forceinline__ RcM5 rc_matrices(const float4* __restrict__ RA0, const float* __restrict__ RB0,
-                                            const float4* __restrict__ RA1, const float* __restrict__ RB1,
-                                            int gx, int gy, int w, int h, float dx, float dy) {
+struct RcGather {
+    float4 q00, q01, q10, q11;
+    float e00, e01, e10, e11;
+    float fx, fy;
+    bool inside;
+};
+
+__device__ __forceinline__ void rc_gather_issue(RcGather& g, const float4* __restrict__ RA1,
+                                                const float* __restrict__ RB1, int gx, int gy, float dx,
+                                                float dy, int w, int h) {
     float fx = gx + dx, fy = gy + dy;
     int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
-    fx -= x1;
-    fy -= y1;
-    size_t p0 = (size_t)gy * w + gx;
-    float4 A0 = RA0[p0];
-    float B0 = RB0[p0];
-    // Branch-free: the four texels are always fetched (from a safe address when the sample
-    // falls outside) and the out-of-range case is a select, so a thread's gathers for several
-    // pixels can all be in flight together.
-    const bool inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
-    const size_t p = inside ? (size_t)y1 * w + x1 : p0;
-    const size_t pw = inside ? (size_t)w : 0, p1 = inside ? 1 : 0;
-    float4 q00 = RA1[p], q01 = RA1[p + p1], q10 = RA1[p + pw], q11 = RA1[p + pw + p1];
-    float e00 = RB1[p], e01 = RB1[p + p1], e10 = RB1[p + pw], e11 = RB1[p + pw + p1];
+    g.fx = fx - x1;
+    g.fy = fy - y1;
+    g.inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+    const size_t p = g.inside ? (size_t)y1 * w + x1 : (size_t)gy * w + gx;
+    const size_t pw = g.inside ? (size_t)w : 0, p1 = g.inside ? 1 : 0;
+    g.q00 = RA1[p]; g.q01 = RA1[p + p1]; g.q10 = RA1[p + pw]; g.q11 = RA1[p + pw + p1];
+    g.e00 = RB1[p]; g.e01 = RB1[p + p1]; g.e10 = RB1[p + pw]; g.e11 = RB1[p + pw + p1];
+}
+
+__device__ __forceinline__ RcM5 rc_matrices_reg(const float4 A0, const float B0, const RcGather& g, float dx,
+                                                float dy, int X, int Y, int w, int h, bool BORDER = true) {
+    float fx = g.fx, fy = g.fy;
     float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy);
     float a10 = (1.f - fx) * fy, a11 = fx * fy;
-    float r2 = a00 * q00.x + a01 * q01.x + a10 * q10.x + a11 * q11.x;
-    float r3 = a00 * q00.y + a01 * q01.y + a10 * q10.y + a11 * q11.y;
-    float r4 = a00 * q00.z + a01 * q01.z + a10 * q10.z + a11 * q11.z;
-    float r5 = a00 * q00.w + a01 * q01.w + a10 * q10.w + a11 * q11.w;
-    float r6 = a00 * e00 + a01 * e01 + a10 * e10 + a11 * e11;
+#define RC_BILIN(c, e) RC_FMA(a11, e##11 c, RC_FMA(a10, e##10 c, RC_FMA(a01, e##01 c, a00 * e##00 c)))
+    float r2 = RC_BILIN(.x, g.q), r3 = RC_BILIN(.y, g.q), r4 = RC_BILIN(.z, g.q), r5 = RC_BILIN(.w, g.q);
+    float r6 = RC_BILIN(, g.e);
+#undef RC_BILIN
     r4 = (A0.z + r4) * 0.5f;
     r5 = (A0.w + r5) * 0.5f;
     r6 = (B0 + r6) * 0.25f;
-    if (!inside) {
+    if (!g.inside) {
         r2 = r3 = 0.f;
         r4 = A0.z;
         r5 = A0.w;
@@ -84,26 +92,36 @@ __device__ __forceinline__ RcM5 rc_matrices(const float4* __restrict__ RA0, cons
     }
     r2 = (A0.x - r2) * 0.5f;
     r3 = (A0.y - r3) * 0.5f;
-    r2 += r4 * dy + r6 * dx;
-    r3 += r6 * dy + r5 * dx;
-    if ((unsigned)(gx - 5) >= (unsigned)(w - 10) || (unsigned)(gy - 5) >= (unsigned)(h - 10)) {
-        // border[5] = {0.14, 0.14, 0.4472, 0.4472, 0.4472}, product over the x and y sides
-        float bl = gx < 5 ? (gx < 2 ? 0.14f : 0.4472f) : 1.f;
-        int rx = w - gx - 1;
-        float br = gx >= w - 5 ? (rx < 2 ? 0.14f : 0.4472f) : 1.f;
-        float bt = gy < 5 ? (gy < 2 ? 0.14f : 0.4472f) : 1.f;
-        int ry = h - gy - 1;
-        float bb = gy >= h - 5 ? (ry < 2 ? 0.14f : 0.4472f) : 1.f;
+    r2 = RC_FMA(r6, dx, RC_FMA(r4, dy, r2));
+    r3 = RC_FMA(r5, dx, RC_FMA(r6, dy, r3));
+    if (BORDER && ((unsigned)(X - 5) >= (unsigned)(w - 10) || (unsigned)(Y - 5) >= (unsigned)(h - 10))) {
+        float bl = X < 5 ? (X < 2 ? 0.14f : 0.4472f) : 1.f;
+        int rx = w - X - 1;
+        float br = X >= w - 5 ? (rx < 2 ? 0.14f : 0.4472f) : 1.f;
+        float bt = Y < 5 ? (Y < 2 ? 0.14f : 0.4472f) : 1.f;
+        int ry = h - Y - 1;
+        float bb = Y >= h - 5 ? (ry < 2 ? 0.14f : 0.4472f) : 1.f;
         float scale = bl * br * bt * bb;
         r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
     }
     RcM5 o;
-    o.m0 = r4 * r4 + r6 * r6;      // G(1,1)
-    o.m1 = (r4 + r5) * r6;         // G(1,2)
-    o.m2 = r5 * r5 + r6 * r6;      // G(2,2)
-    o.m3 = r4 * r2 + r6 * r3;      // h(1)
-    o.m4 = r6 * r2 + r5 * r3;      // h(2)
+    o.m0 = RC_FMA(r4, r4, r6 * r6);
+    o.m1 = (r4 + r5) * r6;
+    o.m2 = RC_FMA(r5, r5, r6 * r6);
+    o.m3 = RC_FMA(r4, r2, r6 * r3);
+    o.m4 = RC_FMA(r6, r2, r5 * r3);
     return o;
+}
+
+__device__ __forceinline__ RcM5 rc_matrices(const float4* __restrict__ RA0, const float* __restrict__ RB0,
+                                            const float4* __restrict__ RA1, const float* __restrict__ RB1,
+                                            int gx, int gy, int w, int h, float dx, float dy) {
+    size_t p0 = (size_t)gy * w + gx;
+    float4 A0 = RA0[p0];
+    float B0 = RB0[p0];
+    RcGather g;
+    rc_gather_issue(g, RA1, RB1, gx, gy, dx, dy, w, h);
+    return rc_matrices_reg(A0, B0, g, dx, dy, gx, gy, w, h);
 }
 
 __device__ __forceinline__ float2 rc_solve(const double* g) {
@@ -361,77 +379,29 @@ __global__ __launch_bounds__(RC_W3_THREADS) void k_flow_iter_w3(RcIterArgs a) {
         }
     }
     // ---- polynomial coefficients: all gathers in flight
-    float4 A0[NIT], q00[NIT], q01[NIT], q10[NIT], q11[NIT];
-    float B0[NIT], e00[NIT], e01[NIT], e10[NIT], e11[NIT];
-    float fxs[NIT], fys[NIT];
-    bool inside[NIT];
+    float4 A0[NIT];
+    float B0[NIT];
+    RcGather gt[NIT];
 #pragma unroll
     for (int q = 0; q < NIT; q++) {
-        float fx = gx[q] + dx[q], fy = gy[q] + dy[q];
-        int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
-        fxs[q] = fx - x1;
-        fys[q] = fy - y1;
         size_t p0 = (size_t)gy[q] * w + gx[q];
-        inside[q] = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
-        const size_t p = inside[q] ? (size_t)y1 * w + x1 : p0;
-        const size_t pw = inside[q] ? (size_t)w : 0, p1 = inside[q] ? 1 : 0;
         A0[q] = RA0[p0];
         B0[q] = RB0[p0];
-        if (a.ablate & 1) {          // ablation: no R1 gathers
-            q00[q] = q01[q] = q10[q] = q11[q] = A0[q];
-            e00[q] = e01[q] = e10[q] = e11[q] = B0[q];
-        } else if (a.ablate & 16) {  // ablation: RA1 gathers only
-            q00[q] = RA1[p]; q01[q] = RA1[p + p1]; q10[q] = RA1[p + pw]; q11[q] = RA1[p + pw + p1];
-            e00[q] = e01[q] = e10[q] = e11[q] = B0[q];
-        } else {
-            q00[q] = RA1[p]; q01[q] = RA1[p + p1]; q10[q] = RA1[p + pw]; q11[q] = RA1[p + pw + p1];
-            e00[q] = RB1[p]; e01[q] = RB1[p + p1]; e10[q] = RB1[p + pw]; e11[q] = RB1[p + pw + p1];
-        }
+        rc_gather_issue(gt[q], RA1, RB1, gx[q], gy[q], dx[q], dy[q], w, h);
     }
-    // ---- FarnebackUpdateMatrices (operation order of optflow.cpp)
+    // ---- FarnebackUpdateMatrices
 #pragma unroll
     for (int q = 0; q < NIT; q++) {
-        float fx = fxs[q], fy = fys[q];
-        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy);
-        float a10 = (1.f - fx) * fy, a11 = fx * fy;
-        float r2 = a00 * q00[q].x + a01 * q01[q].x + a10 * q10[q].x + a11 * q11[q].x;
-        float r3 = a00 * q00[q].y + a01 * q01[q].y + a10 * q10[q].y + a11 * q11[q].y;
-        float r4 = a00 * q00[q].z + a01 * q01[q].z + a10 * q10[q].z + a11 * q11[q].z;
-        float r5 = a00 * q00[q].w + a01 * q01[q].w + a10 * q10[q].w + a11 * q11[q].w;
-        float r6 = a00 * e00[q] + a01 * e01[q] + a10 * e10[q] + a11 * e11[q];
-        r4 = (A0[q].z + r4) * 0.5f;
-        r5 = (A0[q].w + r5) * 0.5f;
-        r6 = (B0[q] + r6) * 0.25f;
-        if (!inside[q]) {
-            r2 = r3 = 0.f;
-            r4 = A0[q].z;
-            r5 = A0[q].w;
-            r6 = B0[q] * 0.5f;
-        }
-        r2 = (A0[q].x - r2) * 0.5f;
-        r3 = (A0[q].y - r3) * 0.5f;
-        r2 += r4 * dy[q] + r6 * dx[q];
-        r3 += r6 * dy[q] + r5 * dx[q];
-        const int X = gx[q], Y = gy[q];
-        if ((unsigned)(X - 5) >= (unsigned)(w - 10) || (unsigned)(Y - 5) >= (unsigned)(h - 10)) {
-            float bl = X < 5 ? (X < 2 ? 0.14f : 0.4472f) : 1.f;
-            int rx = w - X - 1;
-            float br = X >= w - 5 ? (rx < 2 ? 0.14f : 0.4472f) : 1.f;
-            float bt = Y < 5 ? (Y < 2 ? 0.14f : 0.4472f) : 1.f;
-            int ry = h - Y - 1;
-            float bb = Y >= h - 5 ? (ry < 2 ? 0.14f : 0.4472f) : 1.f;
-            float scale = bl * br * bt * bb;
-            r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
-        }
+        RcM5 v = rc_matrices_reg(A0[q], B0[q], gt[q], dx[q], dy[q], gx[q], gy[q], w, h);
         int idx = tid + q * RC_W3_THREADS;
         if (idx < NITEMS) {
             int ly = idx / MW, lx = idx - ly * MW;
             float* mp = Ms + ly * MP + lx;
-            mp[0] = r4 * r4 + r6 * r6;
-            mp[MH * MP] = (r4 + r5) * r6;
-            mp[2 * MH * MP] = r5 * r5 + r6 * r6;
-            mp[3 * MH * MP] = r4 * r2 + r6 * r3;
-            mp[4 * MH * MP] = r6 * r2 + r5 * r3;
+            mp[0] = v.m0;
+            mp[MH * MP] = v.m1;
+            mp[2 * MH * MP] = v.m2;
+            mp[3 * MH * MP] = v.m3;
+            mp[4 * MH * MP] = v.m4;
         }
     }
     __syncthreads();
@@ -492,69 +462,6 @@ static void launch_w3(RcIterArgs a, int pairs, hipStream_t s) {
 // (at p + flow1) hits the lines the first one just brought in.  HBM bytes per pixel drop
 // from 2 x 56 to about 56.  Arithmetic is operation-for-operation that of two launches of
 // k_flow_iter_w3 (bit-identical results).
-struct RcGather {
-    float4 q00, q01, q10, q11;
-    float e00, e01, e10, e11;
-    float fx, fy;
-    bool inside;
-};
-
-__device__ __forceinline__ void rc_gather_issue(RcGather& g, const float4* __restrict__ RA1,
-                                                const float* __restrict__ RB1, int gx, int gy, float dx,
-                                                float dy, int w, int h) {
-    float fx = gx + dx, fy = gy + dy;
-    int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
-    g.fx = fx - x1;
-    g.fy = fy - y1;
-    g.inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
-    const size_t p = g.inside ? (size_t)y1 * w + x1 : (size_t)gy * w + gx;
-    const size_t pw = g.inside ? (size_t)w : 0, p1 = g.inside ? 1 : 0;
-    g.q00 = RA1[p]; g.q01 = RA1[p + p1]; g.q10 = RA1[p + pw]; g.q11 = RA1[p + pw + p1];
-    g.e00 = RB1[p]; g.e01 = RB1[p + p1]; g.e10 = RB1[p + pw]; g.e11 = RB1[p + pw + p1];
-}
-
-__device__ __forceinline__ RcM5 rc_matrices_reg(const float4 A0, const float B0, const RcGather& g, float dx,
-                                                float dy, int X, int Y, int w, int h, bool BORDER = true) {
-    float fx = g.fx, fy = g.fy;
-    float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy);
-    float a10 = (1.f - fx) * fy, a11 = fx * fy;
-    float r2 = a00 * g.q00.x + a01 * g.q01.x + a10 * g.q10.x + a11 * g.q11.x;
-    float r3 = a00 * g.q00.y + a01 * g.q01.y + a10 * g.q10.y + a11 * g.q11.y;
-    float r4 = a00 * g.q00.z + a01 * g.q01.z + a10 * g.q10.z + a11 * g.q11.z;
-    float r5 = a00 * g.q00.w + a01 * g.q01.w + a10 * g.q10.w + a11 * g.q11.w;
-    float r6 = a00 * g.e00 + a01 * g.e01 + a10 * g.e10 + a11 * g.e11;
-    r4 = (A0.z + r4) * 0.5f;
-    r5 = (A0.w + r5) * 0.5f;
-    r6 = (B0 + r6) * 0.25f;
-    if (!g.inside) {
-        r2 = r3 = 0.f;
-        r4 = A0.z;
-        r5 = A0.w;
-        r6 = B0 * 0.5f;
-    }
-    r2 = (A0.x - r2) * 0.5f;
-    r3 = (A0.y - r3) * 0.5f;
-    r2 += r4 * dy + r6 * dx;
-    r3 += r6 * dy + r5 * dx;
-    if (BORDER && ((unsigned)(X - 5) >= (unsigned)(w - 10) || (unsigned)(Y - 5) >= (unsigned)(h - 10))) {
-        float bl = X < 5 ? (X < 2 ? 0.14f : 0.4472f) : 1.f;
-        int rx = w - X - 1;
-        float br = X >= w - 5 ? (rx < 2 ? 0.14f : 0.4472f) : 1.f;
-        float bt = Y < 5 ? (Y < 2 ? 0.14f : 0.4472f) : 1.f;
-        int ry = h - Y - 1;
-        float bb = Y >= h - 5 ? (ry < 2 ? 0.14f : 0.4472f) : 1.f;
-        float scale = bl * br * bt * bb;
-        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
-    }
-    RcM5 o;
-    o.m0 = r4 * r4 + r6 * r6;
-    o.m1 = (r4 + r5) * r6;
-    o.m2 = r5 * r5 + r6 * r6;
-    o.m3 = r4 * r2 + r6 * r3;
-    o.m4 = r6 * r2 + r5 * r3;
-    return o;
-}
-
 // 3x3 window of the five LDS planes around (ly, lx) + solve.
 template <int GAUSS_>
 __device__ __forceinline__ float2 rc_window3_solve(const float* Ms, int plane, int pitch, int ly, int lx,
