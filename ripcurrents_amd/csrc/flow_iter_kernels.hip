@@ -523,7 +523,7 @@ __device__ __forceinline__ void rc_gather_window(RcGather& g, const float4* LA, 
 // served from LDS.  One block = ONE memory round trip: flow_in, R0 and the R1 window do not
 // depend on each other, so all of a thread's global loads are issued before the first use.
 template <int IN_MODE, int GAUSS_, int TW, int TH, int NT, int D>
-__global__ __launch_bounds__(NT) void k_flow_iter2_w3(RcIterArgs a) {
+__global__ __launch_bounds__(NT, 4) void k_flow_iter2_w3(RcIterArgs a) {
     constexpr int MW = TW + 4, MH = TH + 4, MP = MW | 1, PLANE = MH * MP;
     constexpr int NIT = 3, NGRP = (MH + NIT - 1) / NIT;       // a thread owns NIT vertically adjacent pixels
     constexpr int WW = MW + 2 * D, WH = MH + 2 * D, WN = WW * WH, NWL = (WN + NT - 1) / NT;
@@ -627,19 +627,16 @@ __global__ __launch_bounds__(NT) void k_flow_iter2_w3(RcIterArgs a) {
     __syncthreads();      // (the compiler drains the pending LDS-DMA with vmcnt(0) here)
     RC_STAMP(2);
 
-    // ---- iteration 1 matrices (R0 stays in registers for iteration 2)
-    {
-        RcGather g[NIT];
+    // ---- iteration 1 matrices (R0 stays in registers for iteration 2).  The R1 samples come
+    // from LDS, so one pixel at a time is enough and keeps the register count down.
 #pragma unroll
-        for (int q = 0; q < NIT; q++)
-            rc_gather_window<WW, WH>(g[q], LA, LB, ox, oy, RA1, RB1, gxo, RC_GY(q), dx[q], dy[q], w, h);
-#pragma unroll
-        for (int q = 0; q < NIT; q++) {
-            RcM5 v = rc_matrices_reg(A0[q], B0[q], g[q], dx[q], dy[q], gxo, RC_GY(q), w, h, !interior);
-            if (owner && ly0 + q < MH) {
-                float* mp = Ms + (ly0 + q) * MP + lxo;
-                mp[0] = v.m0; mp[PLANE] = v.m1; mp[2 * PLANE] = v.m2; mp[3 * PLANE] = v.m3; mp[4 * PLANE] = v.m4;
-            }
+    for (int q = 0; q < NIT; q++) {
+        RcGather g;
+        rc_gather_window<WW, WH>(g, LA, LB, ox, oy, RA1, RB1, gxo, RC_GY(q), dx[q], dy[q], w, h);
+        RcM5 v = rc_matrices_reg(A0[q], B0[q], g, dx[q], dy[q], gxo, RC_GY(q), w, h, !interior);
+        if (owner && ly0 + q < MH) {
+            float* mp = Ms + (ly0 + q) * MP + lxo;
+            mp[0] = v.m0; mp[PLANE] = v.m1; mp[2 * PLANE] = v.m2; mp[3 * PLANE] = v.m3; mp[4 * PLANE] = v.m4;
         }
     }
     __syncthreads();
@@ -656,7 +653,6 @@ __global__ __launch_bounds__(NT) void k_flow_iter2_w3(RcIterArgs a) {
     // positions that are not iteration-2 pixels (outer ring) -- their results are never stored.
     RcM5 m1[NIT];
     {
-        RcGather g[NIT];
         float gs[NIT][5];
         int rr[NIT + 2];
 #pragma unroll
@@ -687,13 +683,10 @@ __global__ __launch_bounds__(NT) void k_flow_iter2_w3(RcIterArgs a) {
 #pragma unroll
         for (int q = 0; q < NIT; q++) {
             float2 f1 = rc_solve3(gs[q], GAUSS_ ? 1e-3 : a.win.box_eps);
-            dx[q] = f1.x;
-            dy[q] = f1.y;
-            rc_gather_window<WW, WH>(g[q], LA, LB, ox, oy, RA1, RB1, gxo, RC_GY(q), dx[q], dy[q], w, h);
+            RcGather g;
+            rc_gather_window<WW, WH>(g, LA, LB, ox, oy, RA1, RB1, gxo, RC_GY(q), f1.x, f1.y, w, h);
+            m1[q] = rc_matrices_reg(A0[q], B0[q], g, f1.x, f1.y, gxo, RC_GY(q), w, h, !interior);
         }
-#pragma unroll
-        for (int q = 0; q < NIT; q++)
-            m1[q] = rc_matrices_reg(A0[q], B0[q], g[q], dx[q], dy[q], gxo, RC_GY(q), w, h, !interior);
     }
     RC_STAMP(4);
     __syncthreads();      // every thread is done reading M0
