@@ -134,12 +134,19 @@ __device__ __forceinline__ float2 rc_solve(const double* g) {
 
 // 2x2 solve from the UNSCALED window sums: with every g multiplied by s = 1/winsize^2 the
 // factor s^2 cancels except in the +1e-3 regulariser, so eps = 1e-3 / s^2 is used instead.
-// The differences of products (they cancel) are formed in double; the final division is an
-// fp32 reciprocal (1 ulp), far inside the parity tolerance.
-__device__ __forceinline__ float2 rc_solve3(const float* g, double eps) {
-    double g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4];
-    float det = (float)(g0 * g2 - g1 * g1 + eps);
-    float nx = (float)(g0 * g4 - g1 * g3), ny = (float)(g2 * g3 - g1 * g4);
+// The differences of products cancel, so each is formed with Kahan's fma scheme
+// (w = c*d; (fma(a,b,-w)) + fma(-c,d,w): within 1.5 ulp of the exact difference, no doubles);
+// the final division is an fp32 reciprocal (1 ulp).  All far inside the parity tolerance.
+__device__ __forceinline__ float rc_diff_of_products(float a, float b, float c, float d) {
+    float w = c * d;
+    float e = RC_FMA(-c, d, w);
+    float f = RC_FMA(a, b, -w);
+    return f + e;
+}
+__device__ __forceinline__ float2 rc_solve3(const float* g, float eps) {
+    float det = rc_diff_of_products(g[0], g[2], g[1], g[1]) + eps;
+    float nx = rc_diff_of_products(g[0], g[4], g[1], g[3]);
+    float ny = rc_diff_of_products(g[2], g[3], g[1], g[4]);
     float idet = __builtin_amdgcn_rcpf(det);
     return make_float2(nx * idet, ny * idet);
 }
@@ -432,7 +439,7 @@ __global__ __launch_bounds__(RC_W3_THREADS) void k_flow_iter_w3(RcIterArgs a) {
                 else v[j] = col[j][r + 1] + (col[j][r + 2] + col[j][r]);
             }
             if (GAUSS_) g[r][c] = v[1] * a.win.k[0] + a.win.k[1] * (v[0] + v[2]);
-            else g[r][c] = v[1] + (v[2] + v[0]);
+            else g[r][c] = (v[1] + v[0]) + v[2];
         }
     }
     if (ox < w) {
@@ -441,7 +448,7 @@ __global__ __launch_bounds__(RC_W3_THREADS) void k_flow_iter_w3(RcIterArgs a) {
             int oy = ty0 + r0 + r;
             if (oy < h)
                 *(float2*)(fout + (size_t)oy * a.fout_step + (size_t)ox * 8) =
-                    rc_solve3(g[r], GAUSS_ ? 1e-3 : a.win.box_eps);
+                    rc_solve3(g[r], GAUSS_ ? 1e-3f : (float)a.win.box_eps);
         }
     }
 }
@@ -478,9 +485,9 @@ __device__ __forceinline__ float2 rc_window3_solve(const float* Ms, int plane, i
             else v[j] = mid + (dn + up);
         }
         if (GAUSS_) g[c] = v[1] * win.k[0] + win.k[1] * (v[0] + v[2]);
-        else g[c] = v[1] + (v[2] + v[0]);
+        else g[c] = (v[1] + v[0]) + v[2];
     }
-    return rc_solve3(g, GAUSS_ ? 1e-3 : win.box_eps);
+    return rc_solve3(g, GAUSS_ ? 1e-3f : (float)win.box_eps);
 }
 
 // Direct global -> LDS load (no VGPR destination).  `lds_wave_base` is the LDS address for lane 0
@@ -677,12 +684,12 @@ __global__ __launch_bounds__(NT, 4) void k_flow_iter2_w3(RcIterArgs a) {
                     else v[j] = col[j][q + 1] + (col[j][q + 2] + col[j][q]);
                 }
                 if (GAUSS_) gs[q][c] = v[1] * a.win.k[0] + a.win.k[1] * (v[0] + v[2]);
-                else gs[q][c] = v[1] + (v[2] + v[0]);
+                else gs[q][c] = (v[1] + v[0]) + v[2];
             }
         }
 #pragma unroll
         for (int q = 0; q < NIT; q++) {
-            float2 f1 = rc_solve3(gs[q], GAUSS_ ? 1e-3 : a.win.box_eps);
+            float2 f1 = rc_solve3(gs[q], GAUSS_ ? 1e-3f : (float)a.win.box_eps);
             RcGather g;
             rc_gather_window<WW, WH>(g, LA, LB, ox, oy, RA1, RB1, gxo, RC_GY(q), f1.x, f1.y, w, h);
             m1[q] = rc_matrices_reg(A0[q], B0[q], g, f1.x, f1.y, gxo, RC_GY(q), w, h, !interior);
@@ -748,9 +755,273 @@ static void launch_w3x2_t(RcIterArgs a, int pairs, hipStream_t s) {
     hipLaunchKernelGGL((k_flow_iter2_w3<IN_MODE, G, TW, TH, NT, D>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(NT), lds, s, a);
 }
 
+
+// ===================================================================== two iterations, register-resident M
+// Second form of the fused pair of iterations (the one that runs): the M grid of a block is
+// 32 columns wide = half a wave, a thread owns NIT vertically adjacent positions of one column
+// for ALL stages, and M0 / M1 stay in registers.  The 3x3 window is separable in exactly the
+// order of rc_window3_solve: the vertical 3-sum needs only the rows just above and below the
+// thread's own run (exchanged through a small LDS buffer, two rows per group), the horizontal
+// 3-sum takes its neighbours from the adjacent lanes with DPP wave shifts (v_add_f32_dpp), so
+// the five M planes never go through LDS.  Per tile pixel this is ~1.6x fewer VALU and ~3x
+// fewer LDS instructions than k_flow_iter2_w3 and the same bits.
+//   tile = 28 x (8 NIT - 4) outputs, M grid 32 x 8 NIT (halo 2), R1 window = grid +- D in LDS.
+// g[c] = (V[c] + V[c] of lane - 1) + V[c] of lane + 1 for the five planes, as ten v_add_f32_dpp
+// (the compiler's DPP combiner folds only some of the equivalent builtin calls).  s_nop 1 covers
+// the two wait states a DPP read needs after a VALU write of its source.
+__device__ __forceinline__ void rc_hsum3_dpp(float (&g)[5], const float (&V)[5]) {
+    float t0, t1, t2, t3, t4;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %9, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
+        : "v"(V[0]), "v"(V[1]), "v"(V[2]), "v"(V[3]), "v"(V[4]));
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %5, %10 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %6, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %7, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %8, %13 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %9, %14 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4])
+        : "v"(V[0]), "v"(V[1]), "v"(V[2]), "v"(V[3]), "v"(V[4]), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(t4));
+}
+
+
+// s[c] = V[c] of lane - 1  +  V[c] of lane + 1
+__device__ __forceinline__ void rc_hpair_dpp(float (&s)[5], const float (&V)[5]) {
+    float t0, t1, t2, t3, t4;
+    asm("s_nop 1\n\t"
+        "v_mov_b32_dpp %0, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32_dpp %1, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32_dpp %2, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32_dpp %3, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32_dpp %4, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
+        : "v"(V[0]), "v"(V[1]), "v"(V[2]), "v"(V[3]), "v"(V[4]));
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %5, %10 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %6, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %7, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %8, %13 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %9, %14 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3]), "=&v"(s[4])
+        : "v"(V[0]), "v"(V[1]), "v"(V[2]), "v"(V[3]), "v"(V[4]), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(t4));
+}
+
+template <int GAUSS_, int NIT>
+__device__ __forceinline__ void rc_rr_flows(const float (&m)[NIT][5], const float* XR, int grp, int x,
+                                            const RcWindow& win, float2 (&f)[NIT]) {
+    const int gu = max(grp - 1, 0), gd = min(grp + 1, 7);
+    float up[5], dn[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        up[c] = XR[((gu * 2 + 1) * 5 + c) * 32 + x];
+        dn[c] = XR[((gd * 2 + 0) * 5 + c) * 32 + x];
+    }
+    float V[NIT][5];
+#pragma unroll
+    for (int q = 0; q < NIT; q++)
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            float u = q > 0 ? m[q - 1][c] : up[c], d = q < NIT - 1 ? m[q + 1][c] : dn[c];
+            if (GAUSS_) V[q][c] = m[q][c] * win.k[0] + (d + u) * win.k[1];
+            else V[q][c] = m[q][c] + (d + u);
+        }
+#pragma unroll
+    for (int q = 0; q < NIT; q++) {
+        float g[5];
+        if (GAUSS_) {
+            float lr[5];
+            rc_hpair_dpp(lr, V[q]);
+#pragma unroll
+            for (int c = 0; c < 5; c++) g[c] = V[q][c] * win.k[0] + win.k[1] * lr[c];
+        } else {
+            rc_hsum3_dpp(g, V[q]);
+        }
+        f[q] = rc_solve3(g, GAUSS_ ? 1e-3f : (float)win.box_eps);
+    }
+}
+
+template <int NIT>
+__device__ __forceinline__ void rc_rr_exchange(const float (&m)[NIT][5], float* XR, int grp, int x) {
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        XR[((grp * 2 + 0) * 5 + c) * 32 + x] = m[0][c];
+        XR[((grp * 2 + 1) * 5 + c) * 32 + x] = m[NIT - 1][c];
+    }
+}
+
+template <int IN_MODE, int GAUSS_, int NIT, int D, int MINB>
+__global__ __launch_bounds__(256, MINB) void k_flow_iter2_rr(RcIterArgs a) {
+    constexpr int NT = 256, MW = 32, MH = 8 * NIT, TW = MW - 4, TH = MH - 4;
+    constexpr int WW = MW + 2 * D, WH = MH + 2 * D, WN = WW * WH, NWL = (WN + NT - 1) / NT;
+    constexpr int WNP = (WN + 63) & ~63;    // whole waves of LDS-DMA
+    constexpr int MP = MW + 1, PLANE = MH * MP;
+    static_assert(5 * PLANE <= 5 * WNP, "border-block M1 planes alias the R1 window");
+    extern __shared__ __align__(16) float smf[];
+    float4* LA = (float4*)smf;              // [WH][WW]  R1 (y, x, yy, xx)
+    float* LB = smf + 4 * WNP;              // [WH][WW]  R1 xy
+    float* XR = LB + WNP;                   // [8][2][5][32] first / last row of every group
+    float* Ms = smf;                        // border blocks only: [5][MH][MP], after the window is dead
+    const int tid = threadIdx.x;
+    const int z = blockIdx.y;
+    const int t = a.xcd_remap ? rc_xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y) : (int)blockIdx.x;
+    const int tx0 = (t % a.tiles_x) * TW, ty0 = (t / a.tiles_x) * TH;
+    const int w = a.w, h = a.h;
+    const size_t s0 = (size_t)((a.slot0 + z * a.zstep) % a.nslots) * a.R_slot_stride;
+    const size_t s1 = (size_t)((a.slot1 + z * a.zstep) % a.nslots) * a.R_slot_stride;
+    const float4* __restrict__ RA0 = a.RA + s0;  const float* __restrict__ RB0 = a.RB + s0;
+    const float4* __restrict__ RA1 = a.RA + s1;  const float* __restrict__ RB1 = a.RB + s1;
+    const float2* __restrict__ fin = a.fin + (size_t)z * a.fin_pair_stride;
+    char* fout = a.fout + (size_t)z * a.fout_pair_stride;
+    const int ox = tx0 - 2 - D, oy = ty0 - 2 - D;             // window origin (image coordinates)
+
+    const int x = tid & 31, grp = tid >> 5, ly0 = grp * NIT;
+    const int px = tx0 - 2 + x;
+    const int gxo = rc_clampi(px, 0, w - 1);
+    int gys[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; q++) gys[q] = rc_clampi(ty0 - 2 + ly0 + q, 0, h - 1);
+    const bool interior = tx0 - 2 >= 5 && tx0 - 2 + MW <= w - 5 && ty0 - 2 >= 5 && ty0 - 2 + MH <= h - 5;
+
+    // ---- every global load of the block, issued together
+    {
+        const int wave_base = tid & ~63;
+#pragma unroll
+        for (int q = 0; q < NWL; q++) {
+            int idx = tid + q * NT;
+            int wy = idx / WW, wx = idx - wy * WW;
+            int gx = ox + wx, gy = oy + wy;
+            bool ok = idx < WN && (unsigned)gx < (unsigned)w && (unsigned)gy < (unsigned)h;
+            size_t p = ok ? (size_t)gy * w + gx : 0;      // out-of-image texels are never read
+            if (q * NT + wave_base < WN) {
+                rc_glds16(RA1 + p, LA + (q * NT + wave_base));
+                rc_glds4(RB1 + p, LB + (q * NT + wave_base));
+            }
+        }
+    }
+    float4 A0[NIT];
+    float B0[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; q++) {
+        size_t p0 = (size_t)gys[q] * w + gxo;
+        A0[q] = RA0[p0];
+        B0[q] = RB0[p0];
+    }
+    float dx[NIT], dy[NIT];
+    if constexpr (IN_MODE == 0) {
+#pragma unroll
+        for (int q = 0; q < NIT; q++) dx[q] = dy[q] = 0.f;
+    } else if constexpr (IN_MODE == 1) {
+        float2 d[NIT];
+#pragma unroll
+        for (int q = 0; q < NIT; q++) d[q] = fin[(size_t)gys[q] * w + gxo];
+#pragma unroll
+        for (int q = 0; q < NIT; q++) { dx[q] = d[q].x; dy[q] = d[q].y; }
+    } else {
+        float2 p00[NIT], p01[NIT], p10[NIT], p11[NIT];
+        float ax, ay[NIT];
+        const int sx = rc_src_x(gxo, a.up_scale_x, a.fin_w, ax);
+        const int sx1 = min(sx + 1, a.fin_w - 1);
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            int sy = rc_src_y(gys[q], a.up_scale_y, ay[q]);
+            int sy0 = rc_clampi(sy, 0, a.fin_h - 1), sy1 = rc_clampi(sy + 1, 0, a.fin_h - 1);
+            const float2* S0 = fin + (size_t)sy0 * a.fin_w;
+            const float2* S1 = fin + (size_t)sy1 * a.fin_w;
+            p00[q] = S0[sx]; p01[q] = S0[sx1]; p10[q] = S1[sx]; p11[q] = S1[sx1];
+        }
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            float a0 = 1.f - ax, a1 = ax, b0 = 1.f - ay[q], b1 = ay[q];
+            float r0x = p00[q].x * a0 + p01[q].x * a1, r1x = p10[q].x * a0 + p11[q].x * a1;
+            float r0y = p00[q].y * a0 + p01[q].y * a1, r1y = p10[q].y * a0 + p11[q].y * a1;
+            dx[q] = (r0x * b0 + r1x * b1) * a.up_mul;
+            dy[q] = (r0y * b0 + r1y * b1) * a.up_mul;
+        }
+    }
+    __syncthreads();      // (drains the LDS-DMA)
+
+    // ---- M0 on the whole grid, in registers
+    float m[NIT][5];
+#pragma unroll
+    for (int q = 0; q < NIT; q++) {
+        RcGather g;
+        rc_gather_window<WW, WH>(g, LA, LB, ox, oy, RA1, RB1, gxo, gys[q], dx[q], dy[q], w, h);
+        RcM5 v = rc_matrices_reg(A0[q], B0[q], g, dx[q], dy[q], gxo, gys[q], w, h, !interior);
+        m[q][0] = v.m0; m[q][1] = v.m1; m[q][2] = v.m2; m[q][3] = v.m3; m[q][4] = v.m4;
+    }
+    rc_rr_exchange<NIT>(m, XR, grp, x);
+    __syncthreads();
+
+    // ---- flow1 (meaningful on the grid minus its outer ring), then M1 in place of M0
+    {
+        float2 f1[NIT];
+        rc_rr_flows<GAUSS_, NIT>(m, XR, grp, x, a.win, f1);
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            RcGather g;
+            rc_gather_window<WW, WH>(g, LA, LB, ox, oy, RA1, RB1, gxo, gys[q], f1[q].x, f1[q].y, w, h);
+            RcM5 v = rc_matrices_reg(A0[q], B0[q], g, f1[q].x, f1[q].y, gxo, gys[q], w, h, !interior);
+            m[q][0] = v.m0; m[q][1] = v.m1; m[q][2] = v.m2; m[q][3] = v.m3; m[q][4] = v.m4;
+        }
+    }
+    __syncthreads();      // the exchange rows and the R1 window have been read by everyone
+    if (!interior) {
+        // A grid position outside the image stands for the border pixel it replicates (the
+        // window's replicate border): take that pixel's M1.  Block-uniform branch.
+#pragma unroll
+        for (int q = 0; q < NIT; q++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) Ms[c * PLANE + (ly0 + q) * MP + x] = m[q][c];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            const int py = ty0 - 2 + ly0 + q;
+            if ((unsigned)px >= (unsigned)w || (unsigned)py >= (unsigned)h) {
+                const int cx = gxo - (tx0 - 2), cy = gys[q] - (ty0 - 2);
+#pragma unroll
+                for (int c = 0; c < 5; c++) m[q][c] = Ms[c * PLANE + cy * MP + cx];
+            }
+        }
+    }
+    rc_rr_exchange<NIT>(m, XR, grp, x);
+    __syncthreads();
+
+    // ---- flow2 on the tile
+    {
+        float2 f2[NIT];
+        rc_rr_flows<GAUSS_, NIT>(m, XR, grp, x, a.win, f2);
+        if (x >= 2 && x < MW - 2 && px < w) {
+#pragma unroll
+            for (int q = 0; q < NIT; q++) {
+                const int ly = ly0 + q, py = ty0 - 2 + ly;
+                if (ly >= 2 && ly < MH - 2 && py < h)
+                    *(float2*)(fout + (size_t)py * a.fout_step + (size_t)px * 8) = f2[q];
+            }
+        }
+    }
+}
+
+template <int IN_MODE, int G, int NIT, int D, int MINB>
+static void launch_rr_t(RcIterArgs a, int pairs, hipStream_t s) {
+    constexpr int MW = 32, MH = 8 * NIT, TW = MW - 4, TH = MH - 4;
+    a.tw = TW; a.th = TH;
+    a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
+    constexpr int WN = (MW + 2 * D) * (MH + 2 * D), WNP = (WN + 63) & ~63;
+    size_t lds = sizeof(float) * (5 * WNP + 8 * 2 * 5 * 32);
+    hipLaunchKernelGGL((k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(256), lds, s, a);
+}
+
 template <int IN_MODE, int G>
 static void launch_w3x2(RcIterArgs a, int pairs, hipStream_t s) {
-    launch_w3x2_t<IN_MODE, G, 32, 16, 256, 4>(a, pairs, s);
+    if (a.ablate & 64) launch_w3x2_t<IN_MODE, G, 32, 16, 256, 4>(a, pairs, s);   // LDS-resident M (first form)
+    else if (a.ablate & 128) launch_rr_t<IN_MODE, G, 3, 4, 5>(a, pairs, s);     // 28x20 tile, 5 blocks per CU
+    else if (a.ablate & 256) launch_rr_t<IN_MODE, G, 2, 4, 6>(a, pairs, s);     // 28x12 tile, 6 blocks per CU
+    else launch_rr_t<IN_MODE, G, 4, 3, 4>(a, pairs, s);                         // 28x28 tile, 4 blocks per CU
 }
 
 int rc_flow_iter_can_fuse2(const RcIterArgs& a) { return a.win.m == 1 && a.solve; }
