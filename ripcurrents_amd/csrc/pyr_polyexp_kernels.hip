@@ -260,12 +260,12 @@ void rc_launch_pyr(const RcPyrArgs& a, int frames, size_t lds, hipStream_t s) {
 // REFLECT_101; the resize is the identity) into the tile load, so the full-resolution
 // float image never exists in HBM.
 #define RC_POLY_BLOCK 512
-template <int R, int U8>
+template <int R, int U8, int TH>
 __global__ __launch_bounds__(RC_POLY_BLOCK) void k_polyexp(RcPolyArgs a) {
-    constexpr int TW = 64, TH = 32, RP = (R + 3) & ~3;
+    constexpr int TW = 64, RP = (R + 3) & ~3;
     constexpr int INW = TW + 2 * RP, INH = TH + 2 * R;
     constexpr int NV = 4 + 2 * RP;
-    constexpr int UBW = (INW + 2 + 3) & ~3, UBH = INH + 2;
+    constexpr int NDW = (INW + 8) / 4, UBW = 4 * NDW, UBH = INH + 2;   // u8 staging: pitch UBW bytes
     extern __shared__ __align__(16) float smf[];
     float* tin = smf;                // [INH][INW]
     float* hs = smf + INH * INW;     // [3][INH][TW]
@@ -277,52 +277,80 @@ __global__ __launch_bounds__(RC_POLY_BLOCK) void k_polyexp(RcPolyArgs a) {
     float dc;
 
     if constexpr (U8) {
-        unsigned char* ub = (unsigned char*)(hs + 3 * INH * TW);   // [UBH][UBW]
+        // the u8 staging area lives in hs: it is dead before the horizontal pass writes there
+        unsigned char* ub = (unsigned char*)hs;                    // [UBH][UBW]
         const uint8_t* src = a.src8 + (size_t)z * a.src8_frame_stride;
-        const int xlo = rc_clampi(tx0 - RP, 0, w - 1) - 1, ylo = rc_clampi(ty0 - R, 0, h - 1) - 1;
         dc = (float)src[(size_t)min(ty0 + TH / 2, h - 1) * a.src8_step + min(tx0 + TW / 2, w - 1)];
-        {
-            constexpr int NLD = (UBH * UBW + RC_POLY_BLOCK - 1) / RC_POLY_BLOCK;
-            unsigned char v[NLD];
+        const int ylo = rc_clampi(ty0 - R, 0, h - 1) - 1;          // image row of staging row 0
+        const int xs = tx0 - RP - 4;                               // fast path: image column of staging byte 0
+        const bool fast = !a.no_fast_u8 && xs >= 0 && xs + UBW <= w &&
+                          ((((size_t)a.src8) | a.src8_step | a.src8_frame_stride) & 3) == 0;
+        if (fast) {
+            // Tile away from the left/right borders, 4-byte aligned rows: aligned dword loads
+            // (rows reflected), then a 3x3 blur in exact integer arithmetic on packed 16-bit
+            // pairs.  smooth.cpp's float row filter then column filter with (1/4, 1/2, 1/4) is
+            // exact on u8 input (every intermediate is a multiple of 1/16 below 256), so
+            // S / 16 with S = sum of the nine bytes weighted (1 2 1; 2 4 2; 1 2 1) has the same bits.
+            constexpr int NLD = (UBH * NDW + RC_POLY_BLOCK - 1) / RC_POLY_BLOCK;
+            unsigned int v[NLD];
 #pragma unroll
-            for (int q = 0; q < NLD; q++) {     // all loads in flight before the first LDS store
+            for (int q = 0; q < NLD; q++) {
                 int idx = tid + q * RC_POLY_BLOCK;
-                int i = idx / UBW, j = idx - i * UBW;
-                int sy = rc_reflect101(min(ylo + i, h), h), sx = rc_reflect101(min(xlo + j, w), w);
-                v[q] = idx < UBH * UBW ? src[(size_t)sy * a.src8_step + sx] : 0;
+                int i = idx / NDW, j = idx - i * NDW;
+                int sy = rc_reflect101(min(ylo + i, h), h);
+                v[q] = idx < UBH * NDW ? *(const unsigned int*)(src + (size_t)sy * a.src8_step + xs + 4 * j) : 0u;
             }
 #pragma unroll
             for (int q = 0; q < NLD; q++) {
                 int idx = tid + q * RC_POLY_BLOCK;
-                if (idx < UBH * UBW) ub[idx] = v[q];
+                if (idx < UBH * NDW) ((unsigned int*)ub)[idx] = v[q];
             }
-        }
-        __syncthreads();
-        if (tx0 - RP >= 0 && tx0 + TW + RP <= w && ty0 - R >= 0 && ty0 + TH + R <= h) {
-            // interior tile: no clamping, tin(i, j) sits at ub(i + 1, j + 1); one thread blurs
-            // four consecutive pixels from three rows of two aligned dwords each
+            __syncthreads();
+            const float mdc = -dc;
             for (int idx = tid; idx < INH * (INW / 4); idx += RC_POLY_BLOCK) {
                 int i = idx / (INW / 4), j4 = idx - i * (INW / 4);
-                const unsigned int* U = (const unsigned int*)(ub + i * UBW + 4 * j4);
-                float rr[3][4];
+                // tin(i, 4 j4 + p) is centred on staging byte 4 j4 + 4 + p of the row of image line gy
+                int gy = rc_clampi(ty0 - R + i, 0, h - 1);
+                const unsigned int* U = (const unsigned int*)ub + (gy - ylo - 1) * NDW + j4;
+                unsigned int A = 0, B = 0, C = 0, D = 0;
 #pragma unroll
                 for (int t = 0; t < 3; t++) {
-                    unsigned int lo = U[t * (UBW / 4)], hi = U[t * (UBW / 4) + 1];
-                    float b0 = (float)(lo & 255u), b1 = (float)((lo >> 8) & 255u), b2 = (float)((lo >> 16) & 255u),
-                          b3 = (float)(lo >> 24), b4 = (float)(hi & 255u), b5 = (float)((hi >> 8) & 255u);
-                    rr[t][0] = b1 * 0.5f + (b0 + b2) * 0.25f;
-                    rr[t][1] = b2 * 0.5f + (b1 + b3) * 0.25f;
-                    rr[t][2] = b3 * 0.5f + (b2 + b4) * 0.25f;
-                    rr[t][3] = b4 * 0.5f + (b3 + b5) * 0.25f;
+                    unsigned int d0 = U[t * NDW], d1 = U[t * NDW + 1], d2 = U[t * NDW + 2];
+                    // bytes X0..X5 = d0.b3, d1.b0..b3, d2.b0 as 16-bit pairs (low, high)
+                    unsigned int pa = __builtin_amdgcn_perm(d0, d1, 0x0c010c07u);   // (X0, X2)
+                    unsigned int pb = __builtin_amdgcn_perm(d1, d1, 0x0c020c00u);   // (X1, X3)
+                    unsigned int pc = __builtin_amdgcn_perm(d1, d1, 0x0c030c01u);   // (X2, X4)
+                    unsigned int pd = __builtin_amdgcn_perm(d2, d1, 0x0c040c02u);   // (X3, X5)
+                    const int sh = t == 1 ? 1 : 0;
+                    A += pa << sh; B += pb << sh; C += pc << sh; D += pd << sh;
                 }
+                unsigned int o02 = A + 2 * B + C, o13 = B + 2 * C + D;
                 float4 o;
-                o.x = (0.5f * rr[1][0] + 0.25f * (rr[2][0] + rr[0][0])) - dc;
-                o.y = (0.5f * rr[1][1] + 0.25f * (rr[2][1] + rr[0][1])) - dc;
-                o.z = (0.5f * rr[1][2] + 0.25f * (rr[2][2] + rr[0][2])) - dc;
-                o.w = (0.5f * rr[1][3] + 0.25f * (rr[2][3] + rr[0][3])) - dc;
+                o.x = RC_FMA((float)(o02 & 0xffffu), 0.0625f, mdc);
+                o.y = RC_FMA((float)(o13 & 0xffffu), 0.0625f, mdc);
+                o.z = RC_FMA((float)(o02 >> 16), 0.0625f, mdc);
+                o.w = RC_FMA((float)(o13 >> 16), 0.0625f, mdc);
                 *(float4*)(tin + i * INW + 4 * j4) = o;
             }
         } else {
+            const int xlo = rc_clampi(tx0 - RP, 0, w - 1) - 1;
+            constexpr int UBWS = INW + 2;       // bytes used per staging row on this path
+            constexpr int NLD = (UBH * UBWS + RC_POLY_BLOCK - 1) / RC_POLY_BLOCK;
+            unsigned char v[NLD];
+#pragma unroll
+            for (int q = 0; q < NLD; q++) {     // all loads in flight before the first LDS store
+                int idx = tid + q * RC_POLY_BLOCK;
+                int i = idx / UBWS, j = idx - i * UBWS;
+                int sy = rc_reflect101(min(ylo + i, h), h), sx = rc_reflect101(min(xlo + j, w), w);
+                v[q] = idx < UBH * UBWS ? src[(size_t)sy * a.src8_step + sx] : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < NLD; q++) {
+                int idx = tid + q * RC_POLY_BLOCK;
+                int i = idx / UBWS, j = idx - i * UBWS;
+                if (idx < UBH * UBWS) ub[i * UBW + j] = v[q];
+            }
+            __syncthreads();
             for (int idx = tid; idx < INH * INW; idx += RC_POLY_BLOCK) {
                 int i = idx / INW, j = idx - i * INW;
                 int gy = rc_clampi(ty0 - R + i, 0, h - 1), gx = rc_clampi(tx0 - RP + j, 0, w - 1);
@@ -388,6 +416,7 @@ __global__ __launch_bounds__(RC_POLY_BLOCK) void k_polyexp(RcPolyArgs a) {
 
     // vertical pass: lane = column, NR output rows per thread
     constexpr int NR = TH / (RC_POLY_BLOCK / 64);
+    static_assert(NR * (RC_POLY_BLOCK / 64) == TH, "tile height must be a multiple of 8");
     const int x = tid & 63, o0 = (tid >> 6) * NR;
     constexpr int NW = NR + 2 * R;
     float b1[NR], b2[NR], b3[NR], b4[NR], b5[NR], b6[NR];
@@ -458,20 +487,28 @@ __global__ __launch_bounds__(RC_POLY_BLOCK) void k_polyexp(RcPolyArgs a) {
     }
 }
 
-template <int R, int U8>
-static void launch_polyexp_t(const RcPolyArgs& a, int frames, hipStream_t s) {
+template <int R, int U8, int TH>
+static void launch_polyexp_th(const RcPolyArgs& a, int frames, hipStream_t s) {
     constexpr int RP = (R + 3) & ~3;
-    constexpr int INW = 64 + 2 * RP, INH = 32 + 2 * R;
-    size_t lds = sizeof(float) * ((size_t)INH * INW + 3 * (size_t)INH * 64);
-    if (U8) lds += (size_t)(INH + 2) * ((INW + 2 + 3) & ~3);
+    constexpr int INW = 64 + 2 * RP, INH = TH + 2 * R;
+    constexpr size_t lds_hs = sizeof(float) * 3 * (size_t)INH * 64, lds_ub = (size_t)(INH + 2) * (INW + 8);
+    constexpr size_t lds = sizeof(float) * (size_t)INH * INW + (lds_hs > lds_ub ? lds_hs : lds_ub);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_polyexp<R, U8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)k_polyexp<R, U8, TH>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_set = true;
     }
-    dim3 grid((a.w + 63) / 64, (a.h + 31) / 32, frames);
-    hipLaunchKernelGGL((k_polyexp<R, U8>), grid, dim3(RC_POLY_BLOCK), lds, s, a);
+    dim3 grid((a.w + 63) / 64, (a.h + TH - 1) / TH, frames);
+    hipLaunchKernelGGL((k_polyexp<R, U8, TH>), grid, dim3(RC_POLY_BLOCK), lds, s, a);
+}
+
+template <int R, int U8>
+static void launch_polyexp_t(const RcPolyArgs& a, int frames, hipStream_t s) {
+    if constexpr (R <= 9) {
+        if (a.tile_h == 48) { launch_polyexp_th<R, U8, 48>(a, frames, s); return; }
+    }
+    launch_polyexp_th<R, U8, 32>(a, frames, s);
 }
 
 template <int U8>

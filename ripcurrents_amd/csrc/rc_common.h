@@ -70,6 +70,8 @@ struct RcPolyArgs {
     size_t R_slot_stride;     // elements per slot (pixels)
     int slot0, nslots, zstep;
     int w, h;
+    int tile_h;               // rows per block: 32 or 48 (option "poly_tile_h")
+    int no_fast_u8;           // diagnostic: byte-wise staging for every tile
     RcPolyK pk;
 };
 

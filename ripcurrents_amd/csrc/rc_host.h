@@ -73,6 +73,7 @@ struct rc_ctx {
     int exact_taps = 0;
     int fuse_iters = 1;
     int xcd_remap = 1;
+    int poly_tile_h = 32;
     int ablate = 0;
     void* stamps = nullptr;
     int prof_on = 0;

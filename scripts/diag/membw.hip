@@ -1,0 +1,95 @@
+// Memory-system microbenchmarks for MI355X: streaming read (float4 loads, LDS-DMA), write, copy.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_read(const float4* __restrict__ p, size_t n4, float* out) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float acc = 0.f;
+    for (; i + (UNROLL - 1) * stride < n4; i += UNROLL * stride) {
+        float4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) v[u] = p[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+// contiguous chunk per block (tile-like access)
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_read_chunk(const float4* __restrict__ p, size_t n4, float* out) {
+    size_t per = n4 / gridDim.x;
+    const float4* q = p + per * blockIdx.x;
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i + (UNROLL - 1) * 256 < per; i += UNROLL * 256) {
+        float4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) v[u] = q[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+__global__ __launch_bounds__(256) void k_read_dma(const float4* __restrict__ p, size_t n4, float* out) {
+    __shared__ float4 buf[8 * 256];
+    size_t per = n4 / gridDim.x;
+    const float4* q = p + per * blockIdx.x;
+    const int wave_base = threadIdx.x & ~63;
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i + 7 * 256 < per; i += 8 * 256) {
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(q + i + u * 256),
+                                             (__attribute__((address_space(3))) void*)(buf + u * 256 + wave_base), 16, 0, 0);
+        __syncthreads();
+        acc += buf[threadIdx.x].x;
+        __syncthreads();
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+__global__ __launch_bounds__(256) void k_write(float4* __restrict__ p, size_t n4) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) p[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+__global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ s, float4* __restrict__ d, size_t n4) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) d[i] = s[i];
+}
+
+template <class F> static double timeit(F f, int reps) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; i++) f();
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; i++) f();
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / reps * 1e-3;
+}
+
+int main() {
+    const size_t bytes = (size_t)2 << 30;     // 2 GiB, well beyond the 256 MB Infinity Cache
+    const size_t n4 = bytes / 16;
+    float4 *src, *dst; float* out;
+    CK(hipMalloc(&src, bytes)); CK(hipMalloc(&dst, bytes)); CK(hipMalloc(&out, 4));
+    CK(hipMemset(src, 1, bytes)); CK(hipMemset(dst, 0, bytes));
+    for (int rep = 0; rep < 2; rep++) {      // second pass = warm clocks
+        for (int blocks : {1024, 2048, 4096, 8192, 16384, 65536}) {
+            double t1 = timeit([&] { hipLaunchKernelGGL(k_read<1>, dim3(blocks), dim3(256), 0, 0, src, n4, out); }, 10);
+            double t4 = timeit([&] { hipLaunchKernelGGL(k_read<4>, dim3(blocks), dim3(256), 0, 0, src, n4, out); }, 10);
+            double t8 = timeit([&] { hipLaunchKernelGGL(k_read<8>, dim3(blocks), dim3(256), 0, 0, src, n4, out); }, 10);
+            double tc = timeit([&] { hipLaunchKernelGGL(k_read_chunk<8>, dim3(blocks), dim3(256), 0, 0, src, n4, out); }, 10);
+            double td = timeit([&] { hipLaunchKernelGGL(k_read_dma, dim3(blocks), dim3(256), 0, 0, src, n4, out); }, 10);
+            double tw = timeit([&] { hipLaunchKernelGGL(k_write, dim3(blocks), dim3(256), 0, 0, dst, n4); }, 10);
+            double tcp = timeit([&] { hipLaunchKernelGGL(k_copy, dim3(blocks), dim3(256), 0, 0, src, dst, n4); }, 10);
+            printf("blocks %6d  read u1 %.2f  u4 %.2f  u8 %.2f  chunk u8 %.2f  lds-dma %.2f | write %.2f | copy(r+w) %.2f  TB/s\n", blocks,
+                   bytes / t1 * 1e-12, bytes / t4 * 1e-12, bytes / t8 * 1e-12, bytes / tc * 1e-12, bytes / td * 1e-12,
+                   bytes / tw * 1e-12, 2.0 * bytes / tcp * 1e-12);
+            fflush(stdout);
+        }
+    }
+    return 0;
+}
