@@ -25,7 +25,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (scripts/diag/membw.hip on this part: 6.3 TB/s streaming read, 4.5-5.7 write)
 W, H = 1920, 1080
 PARAMS = dict(pyr_scale=0.5, levels=2, winsize=3, iterations=2, poly_n=15, poly_sigma=1.2, flags=0)
 
@@ -63,8 +63,8 @@ def pmc_traffic(kernel, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--pairs", type=int, default=32, help="frame pairs (flow fields) per step")
     ap.add_argument("--chunk", type=int, default=0, help="pairs per launch (0 = library default)")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -199,6 +199,19 @@ def main():
                                    "sample": "%d 1080p frame pairs of the same clip, stateless two-image calls, "
                                              "oracle/farneback_oracle.cpp -O3 single thread (%.1f s)"
                                              % (args.cpu_pairs, cpu_s)}
+            # the same port row-striped over this process's host cores
+            ncores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))   # 16 = one GPU's host share on the pool
+            if ncores > 1:
+                kw = {("iters" if k == "iterations" else k): v for k, v in params.items()}
+                oracle.farneback(host[0], host[1], nthreads=ncores, **kw)
+                tc = time.perf_counter()
+                n_mt = 3 * args.cpu_pairs
+                for t in range(n_mt):
+                    oracle.farneback(host[t % args.cpu_pairs], host[t % args.cpu_pairs + 1], nthreads=ncores, **kw)
+                mt_s = time.perf_counter() - tc
+                out["cpu_baseline"]["all_cores"] = {"value": round(n_mt / mt_s, 4), "unit": "frames/s",
+                                                    "cores": ncores,
+                                                    "sample": "%d pairs, row-striped std::thread (%.1f s)" % (n_mt, mt_s)}
         print(json.dumps(out))
     ctx.close()
     if world > 1:
