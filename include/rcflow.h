@@ -229,6 +229,25 @@ int rcflow_create_edges_dev(rc_ctx* ctx, int stream, const uint8_t* d_outmask, s
 int rcflow_resize_bgr_to_gray_dev(rc_ctx* ctx, int stream, const uint8_t* d_bgr, size_t step,
                                   int sw, int sh, uint8_t* d_gray, size_t gray_step, int dw, int dh);
 
+/* Sparse pyramidal Lucas-Kanade: cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err,
+ * winSize, maxLevel, criteria, flags, minEigThreshold) on 8UC1 device images -- Streakline.cpp:32,
+ * ripcurrents_module.cpp:716, :738, :775, :1162.  d_prev_pts / d_next_pts: npts x (x, y) floats on the
+ * device; d_status npts bytes; d_err npts floats or NULL.  crit_type bit 0 = TermCriteria::COUNT,
+ * bit 1 = EPS; flags: 4 = OPTFLOW_USE_INITIAL_FLOW (d_next_pts is then also an input), 8 =
+ * OPTFLOW_LK_GET_MIN_EIGENVALS.  maxLevel < 8, windows up to 128x128. */
+int rcflow_pyrlk_dev(rc_ctx* ctx, int stream, const uint8_t* d_prev, size_t prev_step,
+                     const uint8_t* d_next, size_t next_step, int w, int h, const float* d_prev_pts,
+                     float* d_next_pts, int npts, uint8_t* d_status, float* d_err, int win_w, int win_h,
+                     int max_level, int crit_type, int max_count, double epsilon, int flags,
+                     double min_eig_threshold);
+/* the same with host pointers (the cv:: signature's form): copies in, tracks, copies out, blocking */
+int rcflow_pyrlk_u8(rc_ctx* ctx, int stream, const uint8_t* prev, size_t prev_step, const uint8_t* next,
+                    size_t next_step, int w, int h, const float* prev_pts, float* next_pts, int npts,
+                    uint8_t* status, float* err, int win_w, int win_h, int max_level, int crit_type,
+                    int max_count, double epsilon, int flags, double min_eig_threshold);
+/* last pyramid level buildOpticalFlowPyramid keeps for this size and window */
+int rcflow_pyrlk_levels(int w, int h, int win_w, int win_h, int max_level);
+
 /* ------------------------------------------------------------------ measurement */
 /* When enabled every kernel launch is bracketed by HIP events on the slot's stream. */
 int rcflow_profile_enable(rc_ctx* ctx, int on);

@@ -46,5 +46,29 @@ inline void calcOpticalFlowFarneback(cv::InputArray _prev, cv::InputArray _next,
     if (rc != RC_OK) CV_Error(rc == RC_EINVAL ? cv::Error::StsBadArg : cv::Error::GpuApiCallError, rcflow_last_error());
 }
 
+// cv::calcOpticalFlowPyrLK with its own signature (Streakline.cpp:32, ripcurrents_module.cpp:716,
+// :738, :775, :1162): 8UC1 images, vector<Point2f> points.
+inline void calcOpticalFlowPyrLK(cv::InputArray _prev, cv::InputArray _next, cv::InputArray _prevPts,
+                                 cv::InputOutputArray _nextPts, cv::OutputArray _status, cv::OutputArray _err,
+                                 cv::Size winSize = cv::Size(21, 21), int maxLevel = 3,
+                                 cv::TermCriteria criteria = cv::TermCriteria(cv::TermCriteria::COUNT + cv::TermCriteria::EPS, 30, 0.01),
+                                 int flags = 0, double minEigThreshold = 1e-4) {
+    cv::Mat prev = _prev.getMat(), next = _next.getMat(), prevPts = _prevPts.getMat();
+    CV_Assert(prev.size() == next.size() && prev.type() == CV_8UC1 && next.type() == CV_8UC1);
+    const int n = prevPts.checkVector(2, CV_32F, true);
+    CV_Assert(n >= 0);
+    if (!(flags & cv::OPTFLOW_USE_INITIAL_FLOW)) _nextPts.create(prevPts.size(), prevPts.type(), -1, true);
+    cv::Mat nextPts = _nextPts.getMat();
+    CV_Assert(nextPts.checkVector(2, CV_32F, true) == n);
+    _status.create(n, 1, CV_8U, -1, true);
+    cv::Mat status = _status.getMat(), err;
+    if (_err.needed()) { _err.create(n, 1, CV_32F, -1, true); err = _err.getMat(); }
+    int rc = rcflow_pyrlk_u8(default_context(prev.cols, prev.rows), 0, prev.data, prev.step, next.data, next.step, prev.cols,
+                             prev.rows, prevPts.ptr<float>(), nextPts.ptr<float>(), n, status.data,
+                             err.empty() ? nullptr : err.ptr<float>(), winSize.width, winSize.height, maxLevel,
+                             criteria.type, criteria.maxCount, criteria.epsilon, flags, minEigThreshold);
+    if (rc != RC_OK) CV_Error(rc == RC_EINVAL ? cv::Error::StsBadArg : cv::Error::GpuApiCallError, rcflow_last_error());
+}
+
 }  // namespace rc
 #endif  // OpenCV present

@@ -100,6 +100,45 @@ class Pipeline {
         }
     }
 
+    // cv::calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts, status, err, winSize, maxLevel,
+    // criteria(type, maxCount, epsilon), flags, minEigThreshold) on 8UC1 frames -- Streakline.cpp:32,
+    // ripcurrents_module.cpp:716, :738, :775, :1162.  criteria type: 1 = COUNT, 2 = EPS.
+    void calcOpticalFlowPyrLK(const Mat& prev, const Mat& next, const std::vector<Pixel2>& prevPts,
+                              std::vector<Pixel2>& nextPts, std::vector<unsigned char>& status, std::vector<float>& err,
+                              int win_w = 21, int win_h = 21, int maxLevel = 3, int crit_type = 3, int maxCount = 30,
+                              double epsilon = 0.01, int flags = 0, double minEigThreshold = 1e-4) {
+        if (prev.empty() || next.empty() || prev.rows != next.rows || prev.cols != next.cols ||
+            prev.channels != 1 || prev.elem != 1 || prev.cols != w_ || prev.rows != h_)
+            throw Error(RC_EINVAL, "calcOpticalFlowPyrLK: prev/next must be 8UC1 of the pipeline's size");
+        const int n = (int)prevPts.size();
+        const bool initial = (flags & 4) != 0;
+        if (initial && (int)nextPts.size() != n) throw Error(RC_EINVAL, "OPTFLOW_USE_INITIAL_FLOW needs nextPts of prevPts' size");
+        nextPts.resize(n); status.assign(n, 0); err.assign(n, 0.f);
+        if (n == 0) return;
+        uint8_t* df = (uint8_t*)d_frames_;
+        hip_check(hipMemcpy2D(df, w_, prev.data, prev.step, w_, h_, hipMemcpyHostToDevice), "upload prev");
+        hip_check(hipMemcpy2D(df + (size_t)w_ * h_, w_, next.data, next.step, w_, h_, hipMemcpyHostToDevice), "upload next");
+        void* d = nullptr;      // prevPts | nextPts | err | status
+        const size_t off_n = (size_t)n * 8, off_e = 2 * off_n, off_s = off_e + (size_t)n * 4;
+        hip_check(hipMalloc(&d, off_s + n), "point buffers");
+        char* b = (char*)d;
+        hipError_t e = hipMemcpy(b, prevPts.data(), off_n, hipMemcpyHostToDevice);
+        if (e == hipSuccess && initial) e = hipMemcpy(b + off_n, nextPts.data(), off_n, hipMemcpyHostToDevice);
+        int rc = e == hipSuccess ? rcflow_pyrlk_dev(ctx_, 0, df, w_, df + (size_t)w_ * h_, w_, w_, h_, (const float*)b,
+                                                    (float*)(b + off_n), n, (uint8_t*)(b + off_s), (float*)(b + off_e), win_w,
+                                                    win_h, maxLevel, crit_type, maxCount, epsilon, flags, minEigThreshold)
+                                 : RC_EHIP;
+        if (rc == RC_OK) rc = rcflow_sync(ctx_, 0);
+        if (rc == RC_OK) {
+            e = hipMemcpy(nextPts.data(), b + off_n, off_n, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(err.data(), b + off_e, (size_t)n * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(status.data(), b + off_s, n, hipMemcpyDeviceToHost);
+        }
+        (void)hipFree(d);
+        check(rc);
+        hip_check(e, "PyrLK point transfer");
+    }
+
     // Replace the resident flow field (e.g. after host-side edits of `current`).
     void upload_flow(const Mat& current) {
         if (current.rows != h_ || current.cols != w_ || current.channels != 2 || current.elem != 4)
@@ -183,9 +222,9 @@ class Pipeline {
     void *d_frames_ = nullptr, *d_flow_ = nullptr, *d_mask_ = nullptr;
 };
 
-// Streakline.hpp:8-20.  runLK's bookkeeping (Streakline.cpp:22-71) with the vertices moved
-// through the dense flow field resident in the pipeline (the main.cpp:961-977 precedent)
-// instead of sparse PyrLK; drawing stays with the caller.
+// Streakline.hpp:8-20.  run(): runLK's bookkeeping (Streakline.cpp:22-71) with the vertices moved
+// through the dense flow field resident in the pipeline (the main.cpp:961-977 precedent);
+// runLK(): the same with the reference's own mover, sparse PyrLK.  Drawing stays with the caller.
 class Streakline {
   public:
     int numberOfVertices;
@@ -206,6 +245,23 @@ class Streakline {
                 next[i] = vertices[i];
         vertices = next;
         vertices.insert(vertices.begin(), generationPoint);   // frameCount % 1 == 0 (Streakline.cpp:46-48)
+        numberOfVertices = (int)vertices.size();
+        frameCount++;
+    }
+
+    // Streakline::runLK(u_prev, u_current, outImg) as the reference runs it: the vertices are
+    // moved by PyrLK (50x50, maxLevel 3, COUNT+EPS 30 / 0.1, flags 10, 1e-4; Streakline.cpp:32).
+    void runLK(Pipeline& pipe, const Mat& u_prev, const Mat& u_current) {
+        std::vector<Pixel2> next;
+        std::vector<unsigned char> status;
+        std::vector<float> err;
+        pipe.calcOpticalFlowPyrLK(u_prev, u_current, vertices, next, status, err, 50, 50, 3, 3, 30, 0.1, 10, 1e-4);
+        for (size_t i = 0; i < next.size(); i++)   // eliminate any large movement (Streakline.cpp:35-40)
+            if (std::fabs(vertices[i].x - next[i].x) > pipe.width() * 0.1 ||
+                std::fabs(vertices[i].y - next[i].y) > pipe.height() * 0.1)
+                next[i] = vertices[i];
+        vertices = next;
+        vertices.insert(vertices.begin(), generationPoint);
         numberOfVertices = (int)vertices.size();
         frameCount++;
     }

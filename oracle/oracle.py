@@ -296,3 +296,63 @@ def resize_bgr_to_gray(bgr, dw, dh):
     lib().orc_resize_bgr_to_gray(_p(bgr, C.c_uint8), C.c_size_t(bgr.strides[0]), sw, sh, _p(gray, C.c_uint8),
                                  C.c_size_t(gray.strides[0]), dw, dh)
     return gray
+
+
+# ---- section 8(f) row 3: sparse pyramidal Lucas-Kanade (lk_oracle.cpp)
+LK_USE_INITIAL_FLOW, LK_GET_MIN_EIGENVALS = 4, 8
+CRIT_COUNT, CRIT_EPS = 1, 2
+
+
+def pyrlk(prev, nxt, prev_pts, next_pts=None, win=(21, 21), max_level=3, crit_type=CRIT_COUNT | CRIT_EPS,
+          max_count=30, epsilon=0.01, flags=0, min_eig_threshold=1e-4):
+    """cv::calcOpticalFlowPyrLK on two HxW uint8 images.  Returns (next_pts, status, err)."""
+    prev = np.ascontiguousarray(prev, dtype=np.uint8)
+    nxt = np.ascontiguousarray(nxt, dtype=np.uint8)
+    h, w = prev.shape
+    p = _f32(prev_pts).reshape(-1, 2)
+    n = p.shape[0]
+    q = np.zeros((n, 2), np.float32) if next_pts is None else _f32(next_pts).reshape(-1, 2).copy()
+    status = np.zeros(n, np.uint8)
+    err = np.zeros(n, np.float32)
+    rc = lib().orc_pyrlk(_p(prev, C.c_uint8), C.c_size_t(prev.strides[0]), _p(nxt, C.c_uint8),
+                         C.c_size_t(nxt.strides[0]), w, h, _p(p), _p(q), n, _p(status, C.c_uint8), _p(err),
+                         win[0], win[1], max_level, crit_type, max_count, C.c_double(epsilon), flags,
+                         C.c_double(min_eig_threshold))
+    if rc != 0:
+        raise ValueError("orc_pyrlk rejected its arguments (rc=%d)" % rc)
+    return q, status, err
+
+
+def pyrlk_levels(w, h, win, max_level):
+    return lib().orc_pyrlk_levels(w, h, win[0], win[1], max_level)
+
+
+def pyrdown_u8(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    lib().orc_pyrdown_u8(_p(img, C.c_uint8), C.c_size_t(img.strides[0]), w, h, _p(out, C.c_uint8),
+                         C.c_size_t(out.strides[0]))
+    return out
+
+
+def scharr_deriv(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w, 2), np.int16)
+    lib().orc_scharr_deriv(_p(img, C.c_uint8), C.c_size_t(img.strides[0]), w, h, _p(out, C.c_int16))
+    return out
+
+
+def streakline_step_lk(verts, nverts, gen, prev, nxt, frame_count):
+    prev = np.ascontiguousarray(prev, dtype=np.uint8)
+    nxt = np.ascontiguousarray(nxt, dtype=np.uint8)
+    h, w = prev.shape
+    n = C.c_int(nverts)
+    fc = C.c_int(frame_count)
+    rc = lib().orc_streakline_step_lk(_p(verts), C.byref(n), C.c_float(gen[0]), C.c_float(gen[1]),
+                                      _p(prev, C.c_uint8), C.c_size_t(prev.strides[0]), _p(nxt, C.c_uint8),
+                                      C.c_size_t(nxt.strides[0]), w, h, C.byref(fc))
+    if rc != 0:
+        raise ValueError("orc_streakline_step_lk failed (rc=%d)" % rc)
+    return n.value, fc.value

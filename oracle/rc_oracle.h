@@ -141,6 +141,22 @@ void orc_ellipse5(uint8_t kernel[25]);   /* getStructuringElement(MORPH_ELLIPSE,
 void orc_resize_bgr_to_gray(const uint8_t* bgr, size_t step, int sw, int sh, uint8_t* gray,
                             size_t gray_step, int dw, int dh);
 
+/* Sparse pyramidal Lucas-Kanade (section 8(f) row 3; lk_oracle.cpp): cv::calcOpticalFlowPyrLK on
+ * 8UC1 images, scalar path of OpenCV 4.1.0 lkpyramid.cpp.  pts are n x (x, y); crit_type bit 0 =
+ * COUNT, bit 1 = EPS (cv::TermCriteria); flags: 4 = OPTFLOW_USE_INITIAL_FLOW, 8 =
+ * OPTFLOW_LK_GET_MIN_EIGENVALS.  Call sites Streakline.cpp:32, ripcurrents_module.cpp:716,738,775,1162. */
+int orc_pyrlk(const uint8_t* prev, size_t prev_step, const uint8_t* next, size_t next_step, int w,
+              int h, const float* prev_pts, float* next_pts, int npts, uint8_t* status, float* err,
+              int win_w, int win_h, int max_level, int crit_type, int max_count, double epsilon,
+              int flags, double min_eig_threshold);
+int orc_pyrlk_levels(int w, int h, int win_w, int win_h, int max_level);  /* last level actually used */
+int orc_pyrdown_u8(const uint8_t* src, size_t step, int w, int h, uint8_t* dst, size_t dst_step);
+int orc_scharr_deriv(const uint8_t* src, size_t step, int w, int h, int16_t* dxy);  /* h*w*2 (dx, dy) */
+/* Streakline::runLK (Streakline.cpp:22-71) with the reference's own mover (PyrLK 50x50, 3 levels) */
+int orc_streakline_step_lk(float* verts, int* nverts, float gen_x, float gen_y, const uint8_t* prev,
+                           size_t prev_step, const uint8_t* next, size_t next_step, int w, int h,
+                           int* frame_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,9 @@ SIGNATURES = {
     "rcflow_shear_rate_to_color_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz, C.POINTER(_f)],
     "rcflow_create_edges_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz],
     "rcflow_resize_bgr_to_gray_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz, _i, _i],
+    "rcflow_pyrlk_dev": [_vp, _i, _vp, _sz, _vp, _sz, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _d],
+    "rcflow_pyrlk_u8": [_vp, _i, _vp, _sz, _vp, _sz, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _d],
+    "rcflow_pyrlk_levels": [_i, _i, _i, _i, _i],
     "rcflow_profile_enable": [_vp, _i],
     "rcflow_profile_reset": [_vp],
     "rcflow_profile_read": [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i), C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)],

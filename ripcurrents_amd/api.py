@@ -441,6 +441,56 @@ class Context:
                                                       self._ptr(out), out.stride(0), dw, dh))
         return out
 
+    def calcOpticalFlowPyrLK(self, prev, nxt, prev_pts, next_pts=None, win=(21, 21), max_level=3,
+                             crit_type=3, max_count=30, epsilon=0.01, flags=0, min_eig_threshold=1e-4, stream=0):
+        """cv::calcOpticalFlowPyrLK on 8UC1 images (Streakline.cpp:32, ripcurrents_module.cpp:716,738,775,
+        1162).  crit_type: 1 = COUNT, 2 = EPS; flags: 4 = OPTFLOW_USE_INITIAL_FLOW, 8 =
+        OPTFLOW_LK_GET_MIN_EIGENVALS.  Returns (next_pts [n,2] f32, status [n] u8, err [n] f32) on the device."""
+        a = self._dev(prev, torch.uint8)
+        b = self._dev(nxt, torch.uint8)
+        if a.stride(1) != 1:
+            a = a.contiguous()
+        if b.stride(1) != 1:
+            b = b.contiguous()
+        h, w = a.shape
+        if tuple(b.shape) != (h, w):
+            raise ValueError("prev and next differ in size")
+        p = self._dev(prev_pts, torch.float32).reshape(-1, 2).contiguous()
+        n = p.shape[0]
+        if next_pts is None:
+            q = torch.zeros((n, 2), dtype=torch.float32, device=self.device)
+        else:
+            q = self._dev(next_pts, torch.float32).reshape(-1, 2).contiguous().clone()
+        status = torch.zeros((n,), dtype=torch.uint8, device=self.device)
+        err = torch.zeros((n,), dtype=torch.float32, device=self.device)
+        self._bind(stream)
+        check(self._lib.rcflow_pyrlk_dev(self._h, stream, self._ptr(a), a.stride(0), self._ptr(b), b.stride(0), w, h,
+                                         self._ptr(p), self._ptr(q), n, self._ptr(status), self._ptr(err),
+                                         int(win[0]), int(win[1]), int(max_level), int(crit_type), int(max_count),
+                                         float(epsilon), int(flags), float(min_eig_threshold)))
+        return q, status, err
+
+    def calcOpticalFlowPyrLK_host(self, prev, nxt, prev_pts, win=(21, 21), max_level=3, crit_type=3, max_count=30,
+                                  epsilon=0.01, flags=0, min_eig_threshold=1e-4, stream=0):
+        """Host-pointer form (rcflow_pyrlk_u8): numpy in, numpy out, blocking."""
+        a = np.ascontiguousarray(prev, np.uint8)
+        b = np.ascontiguousarray(nxt, np.uint8)
+        h, w = a.shape
+        p = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+        n = p.shape[0]
+        q = np.zeros((n, 2), np.float32)
+        status = np.zeros(n, np.uint8)
+        err = np.zeros(n, np.float32)
+        self._bind(stream)
+        check(self._lib.rcflow_pyrlk_u8(self._h, stream, a.ctypes.data, a.strides[0], b.ctypes.data, b.strides[0], w, h,
+                                        p.ctypes.data, q.ctypes.data, n, status.ctypes.data, err.ctypes.data,
+                                        int(win[0]), int(win[1]), int(max_level), int(crit_type), int(max_count),
+                                        float(epsilon), int(flags), float(min_eig_threshold)))
+        return q, status, err
+
+    def pyrlk_levels(self, w, h, win, max_level):
+        return check(self._lib.rcflow_pyrlk_levels(w, h, int(win[0]), int(win[1]), int(max_level)))
+
     # ------------------------------------------------------------------ measurement
     def profile_enable(self, on=True):
         check(self._lib.rcflow_profile_enable(self._h, 1 if on else 0))
@@ -488,6 +538,22 @@ class Streakline:
         # variant 4 = `p += delta*dt/iterations` with no cutoff; one step
         moved, _ = ctx.streamline(v, flow, dt, 1, 0.0, variant=4, stream=stream)
         nxt = moved.cpu().numpy()
+        big = (np.abs(v[:, 0] - nxt[:, 0]) > width * 0.1) | (np.abs(v[:, 1] - nxt[:, 1]) > height * 0.1)
+        nxt[big] = v[big]
+        self.vertices = [self.generationPoint] + [tuple(map(float, p)) for p in nxt]
+        self.numberOfVertices = len(self.vertices)
+        self.frameCount += 1
+        return self.vertices
+
+    def runLK(self, ctx, u_prev, u_current, stream=0):
+        """Streakline::runLK (Streakline.cpp:22-71) with the reference's own mover: PyrLK 50x50, maxLevel 3,
+        COUNT+EPS (30, 0.1), flags 10, minEigThreshold 1e-4 (:32); XDIM/YDIM are the frame size."""
+        height, width = u_prev.shape[:2]
+        v = np.asarray(self.vertices, np.float32).reshape(-1, 2)
+        q, _, _ = ctx.calcOpticalFlowPyrLK(u_prev, u_current, v, win=(50, 50), max_level=3, crit_type=3,
+                                           max_count=30, epsilon=0.1, flags=10, min_eig_threshold=1e-4,
+                                           stream=stream)
+        nxt = q.cpu().numpy()
         big = (np.abs(v[:, 0] - nxt[:, 0]) > width * 0.1) | (np.abs(v[:, 1] - nxt[:, 1]) > height * 0.1)
         nxt[big] = v[big]
         self.vertices = [self.generationPoint] + [tuple(map(float, p)) for p in nxt]
