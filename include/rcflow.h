@@ -229,6 +229,22 @@ int rcflow_create_edges_dev(rc_ctx* ctx, int stream, const uint8_t* d_outmask, s
 int rcflow_resize_bgr_to_gray_dev(rc_ctx* ctx, int stream, const uint8_t* d_bgr, size_t step,
                                   int sw, int sh, uint8_t* d_gray, size_t gray_step, int dw, int dh);
 
+/* Display path, ripcurrents.cpp:233-273 (= streamline_displacement / _total_motion / _ratio /
+ * _positions, ripcurrents_module.cpp:13-60) on the slot's streamline field (rcflow_advect_field_dev):
+ * which 0 = |pt|, 1 = dist, 2 = |pt| / dist; minMaxLoc + convertTo(CV_8UC1, 255/max) +
+ * applyColorMap(COLORMAP_JET) -> 8UC3 BGR.  max_out (host, may be NULL) receives the maximum (blocks). */
+int rcflow_streamline_display_dev(rc_ctx* ctx, int stream, int which, uint8_t* d_bgr, size_t bgr_step,
+                                  float* max_out);
+/* marks (1,1,1) in a 32FC3 image where each pixel's particle sits (:44-60); the caller zeroes it */
+int rcflow_streamline_positions_dev(rc_ctx* ctx, int stream, float* d_density, size_t density_step);
+/* cvtColor(current, current, CV_HSV2BGR) on the 32FC3 display image (ripcurrents.cpp:405); H in degrees */
+int rcflow_hsv_to_bgr_dev(rc_ctx* ctx, int stream, const float* d_hsv, size_t hsv_step, int w, int h,
+                          float* d_bgr, size_t bgr_step);
+/* frame size of the slot's analysis state (0, 0 before rcflow_analysis_reset / the first analysis call) */
+int rcflow_analysis_size(rc_ctx* ctx, int stream, int* w, int* h);
+/* the 256 x BGR table of applyColorMap(COLORMAP_JET) (host) */
+int rcflow_jet_lut(uint8_t* lut_bgr /* 768 */);
+
 /* Sparse pyramidal Lucas-Kanade: cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err,
  * winSize, maxLevel, criteria, flags, minEigThreshold) on 8UC1 device images -- Streakline.cpp:32,
  * ripcurrents_module.cpp:716, :738, :775, :1162.  d_prev_pts / d_next_pts: npts x (x, y) floats on the

@@ -179,6 +179,13 @@ class Pipeline {
         check(rcflow_advect_field_read(ctx_, 0, (float*)streamlines_mat, streamlines_distance));
     }
 
+    // streamline_displacement / streamline_total_motion / streamline_ratio
+    // (ripcurrents_module.cpp:13-40, ripcurrents.cpp:233-257) on the resident streamline field:
+    // streamoverlay_color must be 8UC3 of the frame size; only that image crosses PCIe.
+    void streamline_displacement(Mat& streamoverlay_color) { display(0, streamoverlay_color); }
+    void streamline_total_motion(Mat& streamoverlay_color) { display(1, streamoverlay_color); }
+    void streamline_ratio(Mat& streamoverlay_color) { display(2, streamoverlay_color); }
+
     // for (s...) streamline(streampt + s, color, current, overlay, dt, iterations, UPPER, ...):
     // advances the seeds; `trace` (optional, n*iterations points) is what the host draws with
     // cv::line.  variant: see rcflow_advect_points_dev.
@@ -216,6 +223,19 @@ class Pipeline {
         d_frames_ = d_flow_ = d_mask_ = nullptr;
         if (ctx_) rcflow_destroy(ctx_);
         ctx_ = nullptr;
+    }
+    void display(int which, Mat& bgr) {
+        if (bgr.rows != h_ || bgr.cols != w_ || bgr.channels != 3 || bgr.elem != 1)
+            throw Error(RC_EINVAL, "streamoverlay_color must be 8UC3 of the frame size");
+        void* d = nullptr;
+        hip_check(hipMalloc(&d, (size_t)w_ * h_ * 3), "hipMalloc display image");
+        int rc = rcflow_streamline_display_dev(ctx_, 0, which, (uint8_t*)d, (size_t)w_ * 3, nullptr);
+        if (rc == RC_OK) rc = rcflow_sync(ctx_, 0);
+        hipError_t e = rc == RC_OK ? hipMemcpy2D(bgr.data, bgr.step, d, (size_t)w_ * 3, (size_t)w_ * 3, h_, hipMemcpyDeviceToHost)
+                                   : hipSuccess;
+        (void)hipFree(d);
+        check(rc);
+        hip_check(e, "download display image");
     }
     rc_ctx* ctx_ = nullptr;
     int w_, h_;

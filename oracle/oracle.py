@@ -356,3 +356,36 @@ def streakline_step_lk(verts, nverts, gen, prev, nxt, frame_count):
     if rc != 0:
         raise ValueError("orc_streakline_step_lk failed (rc=%d)" % rc)
     return n.value, fc.value
+
+
+# ---- section 8(f) row 4: display path (display_oracle.cpp)
+def jet_lut():
+    lut = np.zeros((256, 3), np.uint8)
+    lib().orc_jet_lut(_p(lut, C.c_uint8))
+    return lut
+
+
+def streamline_display(pt, dist, which):
+    pt, dist = _f32(pt), _f32(dist)
+    h, w = dist.shape
+    bgr = np.zeros((h, w, 3), np.uint8)
+    mx = C.c_double(0)
+    lib().orc_streamline_display(_p(pt), C.c_size_t(pt.strides[0]), _p(dist), C.c_size_t(dist.strides[0]), w, h,
+                                 which, _p(bgr, C.c_uint8), C.c_size_t(bgr.strides[0]), C.byref(mx))
+    return bgr, mx.value
+
+
+def streamline_positions(pt):
+    pt = _f32(pt)
+    h, w = pt.shape[:2]
+    den = np.zeros((h, w, 3), np.float32)
+    lib().orc_streamline_positions(_p(pt), C.c_size_t(pt.strides[0]), w, h, _p(den), C.c_size_t(den.strides[0]))
+    return den
+
+
+def hsv_to_bgr(hsv):
+    hsv = _f32(hsv)
+    h, w = hsv.shape[:2]
+    out = np.zeros((h, w, 3), np.float32)
+    lib().orc_hsv_to_bgr_f32(_p(hsv), C.c_size_t(hsv.strides[0]), w, h, _p(out), C.c_size_t(out.strides[0]))
+    return out

@@ -141,6 +141,16 @@ void orc_ellipse5(uint8_t kernel[25]);   /* getStructuringElement(MORPH_ELLIPSE,
 void orc_resize_bgr_to_gray(const uint8_t* bgr, size_t step, int sw, int sh, uint8_t* gray,
                             size_t gray_step, int dw, int dh);
 
+/* Display path (section 8(f) row 4; display_oracle.cpp): ripcurrents.cpp:233-273 and :405 */
+void orc_jet_lut(uint8_t* lut_bgr /* 256*3: applyColorMap(COLORMAP_JET) */);
+/* which 0 = streamline_displacement, 1 = streamline_total_motion, 2 = streamline_ratio
+ * (ripcurrents_module.cpp:13-40): minMaxLoc + convertTo(8U, 255/max) + JET -> 8UC3 BGR */
+void orc_streamline_display(const float* pt, size_t pt_step, const float* dist, size_t dist_step, int w,
+                            int h, int which, uint8_t* bgr, size_t bgr_step, double* max_out);
+void orc_streamline_positions(const float* pt, size_t pt_step, int w, int h, float* density,
+                              size_t density_step);                       /* :44-60, 32FC3 */
+void orc_hsv_to_bgr_f32(const float* hsv, size_t hsv_step, int w, int h, float* bgr, size_t bgr_step);
+
 /* Sparse pyramidal Lucas-Kanade (section 8(f) row 3; lk_oracle.cpp): cv::calcOpticalFlowPyrLK on
  * 8UC1 images, scalar path of OpenCV 4.1.0 lkpyramid.cpp.  pts are n x (x, y); crit_type bit 0 =
  * COUNT, bit 1 = EPS (cv::TermCriteria); flags: 4 = OPTFLOW_USE_INITIAL_FLOW, 8 =

@@ -77,6 +77,11 @@ SIGNATURES = {
     "rcflow_shear_rate_to_color_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz, C.POINTER(_f)],
     "rcflow_create_edges_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz],
     "rcflow_resize_bgr_to_gray_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz, _i, _i],
+    "rcflow_streamline_display_dev": [_vp, _i, _i, _vp, _sz, C.POINTER(_f)],
+    "rcflow_streamline_positions_dev": [_vp, _i, _vp, _sz],
+    "rcflow_hsv_to_bgr_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz],
+    "rcflow_jet_lut": [_vp],
+    "rcflow_analysis_size": [_vp, _i, C.POINTER(_i), C.POINTER(_i)],
     "rcflow_pyrlk_dev": [_vp, _i, _vp, _sz, _vp, _sz, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _d],
     "rcflow_pyrlk_u8": [_vp, _i, _vp, _sz, _vp, _sz, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _d],
     "rcflow_pyrlk_levels": [_i, _i, _i, _i, _i],

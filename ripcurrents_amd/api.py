@@ -441,6 +441,47 @@ class Context:
                                                       self._ptr(out), out.stride(0), dw, dh))
         return out
 
+    def _an_size(self, stream):
+        w, h = C.c_int(0), C.c_int(0)
+        check(self._lib.rcflow_analysis_size(self._h, stream, C.byref(w), C.byref(h)))
+        if w.value <= 0 or h.value <= 0:
+            raise RuntimeError("the slot has no analysis state yet")
+        return w.value, h.value
+
+    def streamline_display(self, which, stream=0):
+        """streamline_displacement (0) / _total_motion (1) / _ratio (2), ripcurrents_module.cpp:13-40, on the
+        slot's streamline field: returns (8UC3 BGR image on the device, the minMaxLoc maximum)."""
+        w, h = self._an_size(stream)
+        out = torch.empty((h, w, 3), dtype=torch.uint8, device=self.device)
+        mx = C.c_float(0)
+        self._bind(stream)
+        check(self._lib.rcflow_streamline_display_dev(self._h, stream, int(which), self._ptr(out), out.stride(0),
+                                                      C.byref(mx)))
+        return out, mx.value
+
+    def streamline_positions(self, stream=0):
+        """streamline_positions ripcurrents_module.cpp:44-60: 32FC3 image, (1,1,1) where particles sit."""
+        w, h = self._an_size(stream)
+        out = torch.zeros((h, w, 3), dtype=torch.float32, device=self.device)
+        self._bind(stream)
+        check(self._lib.rcflow_streamline_positions_dev(self._h, stream, self._ptr(out), out.stride(0) * 4))
+        return out
+
+    def hsv_to_bgr(self, hsv, stream=0):
+        """cvtColor(current, current, CV_HSV2BGR) on the 32FC3 display image (ripcurrents.cpp:405)."""
+        a = self._dev(hsv, torch.float32).contiguous()
+        h, w = a.shape[:2]
+        out = torch.empty_like(a)
+        self._bind(stream)
+        check(self._lib.rcflow_hsv_to_bgr_dev(self._h, stream, self._ptr(a), a.stride(0) * 4, w, h, self._ptr(out),
+                                              out.stride(0) * 4))
+        return out
+
+    def jet_lut(self):
+        lut = np.zeros((256, 3), np.uint8)
+        check(self._lib.rcflow_jet_lut(lut.ctypes.data))
+        return lut
+
     def calcOpticalFlowPyrLK(self, prev, nxt, prev_pts, next_pts=None, win=(21, 21), max_level=3,
                              crit_type=3, max_count=30, epsilon=0.01, flags=0, min_eig_threshold=1e-4, stream=0):
         """cv::calcOpticalFlowPyrLK on 8UC1 images (Streakline.cpp:32, ripcurrents_module.cpp:716,738,775,

@@ -985,3 +985,201 @@ extern "C" int rcflow_resize_bgr_to_gray_dev(rc_ctx* ctx, int stream, const uint
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
+
+// ===================================================================== SURVEY 8(f) row 4: display path
+// ripcurrents.cpp:233-273 (ripcurrents_module.cpp:13-60) and :405.  Only 8-bit BGR images (and the
+// float "flow" window) leave the device.
+//   k_display_max     minMaxLoc maximum of |pt|, dist or |pt|/dist (NaNs never win)          -> scratch
+//   k_display_map     convertTo(8U, 255/max) + applyColorMap(COLORMAP_JET)                    -> 8UC3
+//   k_positions       streamline_positions scatter                                            -> 32FC3
+//   k_hsv_to_bgr      cvtColor(32FC3, CV_HSV2BGR)                                             -> 32FC3
+__device__ __forceinline__ float rc_display_value(const float2* pt, const float* dist, size_t i, int which) {
+    const float2 p = pt[i];
+    const float mag = sqrtf(p.x * p.x + p.y * p.y);          // cv::magnitude
+    return which == 0 ? mag : (which == 1 ? dist[i] : mag / dist[i]);
+}
+
+__global__ __launch_bounds__(RC_BLOCK) void k_display_max(const float2* __restrict__ pt, const float* __restrict__ dist,
+                                                          size_t n, int which, unsigned int* out) {
+    __shared__ float red[RC_BLOCK];
+    float m = -INFINITY;
+    for (size_t i = (size_t)blockIdx.x * RC_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * RC_BLOCK) {
+        float v = rc_display_value(pt, dist, i, which);
+        if (v > m) m = v;                                      // false for NaN, like minMaxLoc
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = RC_BLOCK / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s && red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s];
+        __syncthreads();
+    }
+    // every value is >= 0 (or -inf when nothing compared greater): order-preserving integer key
+    if (threadIdx.x == 0) {
+        float r = red[0];
+        unsigned int key = r >= 0.f ? __float_as_uint(r) + 0x80000000u : ~__float_as_uint(r);
+        atomicMax(out, key);
+    }
+}
+
+__global__ __launch_bounds__(RC_BLOCK) void k_display_map(const float2* __restrict__ pt, const float* __restrict__ dist,
+                                                          int w, int h, int which, const unsigned int* maxkey,
+                                                          const uint8_t* __restrict__ lut, uint8_t* bgr, size_t bgr_step) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const unsigned int key = *maxkey;
+    const float mx = __uint_as_float(key & 0x80000000u ? key - 0x80000000u : ~key);
+    const float alpha = (float)(255 / (double)mx);
+    const float v = rc_display_value(pt, dist, (size_t)y * w + x, which) * alpha;
+    // saturate_cast<uchar>(cvRound(v)): NaN / out-of-range convert to INT_MIN -> 0
+    int idx = fabsf(v) < 2147483648.f ? (int)rintf(v) : (int)0x80000000;
+    idx = idx < 0 ? 0 : (idx > 255 ? 255 : idx);
+    uint8_t* o = bgr + (size_t)y * bgr_step + 3 * x;
+    o[0] = lut[3 * idx]; o[1] = lut[3 * idx + 1]; o[2] = lut[3 * idx + 2];
+}
+
+__global__ __launch_bounds__(RC_BLOCK) void k_positions(const float2* __restrict__ pt, int w, int h, float* density,
+                                                        size_t density_step) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float2 p = pt[(size_t)y * w + x];
+    const int xind = (int)roundf(floorf(p.x + x)), yind = (int)roundf(floorf(p.y + y));
+    if (xind < 1 || yind < 1 || xind + 2 > w || yind + 2 > h) return;
+    float* d = (float*)((char*)density + (size_t)yind * density_step) + 3 * xind;
+    d[0] = 1.f; d[1] = 1.f; d[2] = 1.f;        // every writer stores the same value: order is irrelevant
+}
+
+__global__ __launch_bounds__(RC_BLOCK) void k_hsv_to_bgr(const float* __restrict__ hsv, size_t hsv_step, int w, int h,
+                                                         float* bgr, size_t bgr_step) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float* s = (const float*)((const char*)hsv + (size_t)y * hsv_step) + 3 * x;
+    float hh = s[0];
+    const float ss = s[1], vv = s[2];
+    float b, g, r;
+    if (ss == 0) b = g = r = vv;
+    else {
+        hh *= 6.f / 360.f;
+        if (hh < 0) do hh += 6; while (hh < 0);
+        else if (hh >= 6) do hh -= 6; while (hh >= 6);
+        int sector = (int)floorf(hh);
+        hh -= sector;
+        if ((unsigned)sector >= 6u) { sector = 0; hh = 0.f; }
+        const float t0 = vv, t1 = vv * (1.f - ss), t2 = vv * (1.f - ss * hh), t3 = vv * (1.f - ss * (1.f - hh));
+        // sector_data = {1,3,0},{1,0,2},{3,0,1},{0,2,1},{0,1,3},{2,1,0}  (b, g, r)
+        switch (sector) {
+            case 0: b = t1; g = t3; r = t0; break;
+            case 1: b = t1; g = t0; r = t2; break;
+            case 2: b = t3; g = t0; r = t1; break;
+            case 3: b = t0; g = t2; r = t1; break;
+            case 4: b = t0; g = t1; r = t3; break;
+            default: b = t2; g = t1; r = t0; break;
+        }
+    }
+    float* d = (float*)((char*)bgr + (size_t)y * bgr_step) + 3 * x;
+    d[0] = b; d[1] = g; d[2] = r;
+}
+
+// applyColorMap(COLORMAP_JET): colormap.cpp tabulates clip(1.5 - |4x - c|, 0, 1), x = i/255, c = 3, 2, 1
+// for r, g, b as float literals and passes them through linear_colormap (float interp1 onto
+// linspace(0,1,256), then convertTo(8U, 255)).
+extern "C" int rcflow_jet_lut(uint8_t* lut_bgr) {
+    if (!lut_bgr) return RC_EINVAL;
+    float tab[3][256], X[256];
+    const float step = (1.f - 0.f) / (256 - 1);
+    for (int i = 0; i < 256; i++) {
+        double x = i / 255.0;
+        X[i] = 0.f + i * step;
+        for (int c = 0; c < 3; c++) {           // b, g, r
+            double v = 1.5 - fabs(4 * x - (c + 1));
+            tab[c][i] = (float)(v < 0 ? 0 : (v > 1 ? 1 : v));
+        }
+    }
+    for (int i = 0; i < 256; i++) {
+        const float xi = X[i];
+        int low = 0, high = 255;
+        if (xi < X[low]) high = 1;
+        if (xi > X[high]) low = high - 1;
+        while (high - low > 1) {
+            int c = low + ((high - low) >> 1);
+            if (xi > X[c]) low = c; else high = c;
+        }
+        for (int c = 0; c < 3; c++) {
+            const float* Y = tab[c];
+            float yi = Y[low] + (xi - X[low]) * (Y[high] - Y[low]) / (X[high] - X[low]);
+            int q = (int)nearbyintf(yi * 255.f);
+            lut_bgr[3 * i + c] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+        }
+    }
+    return RC_OK;
+}
+
+static int display_lut(RcSlot& s) {
+    if (s.an.jet.p) return RC_OK;
+    int rc = rc_buf_ensure(s.an.jet, 768 + 16);
+    if (rc) return rc;
+    uint8_t lut[768];
+    rcflow_jet_lut(lut);
+    RC_HIP(hipMemcpy(s.an.jet.p, lut, 768, hipMemcpyHostToDevice));
+    return RC_OK;
+}
+
+extern "C" int rcflow_streamline_display_dev(rc_ctx* ctx, int stream, int which, uint8_t* d_bgr, size_t bgr_step,
+                                             float* max_out) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    if (!s->an.pt.p || !s->an.dist.p) { rc_set_error("no streamline field in this slot (rcflow_advect_field_dev first)"); return RC_ESTATE; }
+    const int w = s->an.w, h = s->an.h;
+    if (which < 0 || which > 2 || !d_bgr || bgr_step < (size_t)w * 3) { rc_set_error("bad display arguments"); return RC_EINVAL; }
+    RC_HIP(hipSetDevice(ctx->device));
+    int rc = display_lut(*s);
+    if (rc) return rc;
+    unsigned int* key = (unsigned int*)((uint8_t*)s->an.jet.p + 768);
+    RC_HIP(hipMemsetAsync(key, 0, 4, s->cur));
+    const size_t n = (size_t)w * h;
+    hipLaunchKernelGGL(k_display_max, dim3(1024), dim3(RC_BLOCK), 0, s->cur, (const float2*)s->an.pt.p,
+                       (const float*)s->an.dist.p, n, which, key);
+    hipLaunchKernelGGL(k_display_map, dim3((w + 63) / 64, (h + 3) / 4), dim3(RC_BLOCK), 0, s->cur,
+                       (const float2*)s->an.pt.p, (const float*)s->an.dist.p, w, h, which, key,
+                       (const uint8_t*)s->an.jet.p, d_bgr, bgr_step);
+    RC_HIP(hipGetLastError());
+    if (max_out) {
+        unsigned int k = 0;
+        RC_HIP(hipMemcpyAsync(&k, key, 4, hipMemcpyDeviceToHost, s->cur));
+        RC_HIP(hipStreamSynchronize(s->cur));
+        unsigned int bits = (k & 0x80000000u) ? k - 0x80000000u : ~k;
+        memcpy(max_out, &bits, 4);
+    }
+    return RC_OK;
+}
+
+extern "C" int rcflow_streamline_positions_dev(rc_ctx* ctx, int stream, float* d_density, size_t density_step) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    if (!s->an.pt.p) { rc_set_error("no streamline field in this slot"); return RC_ESTATE; }
+    const int w = s->an.w, h = s->an.h;
+    if (!d_density || density_step < (size_t)w * 12) return RC_EINVAL;
+    RC_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_positions, dim3((w + 63) / 64, (h + 3) / 4), dim3(RC_BLOCK), 0, s->cur, (const float2*)s->an.pt.p,
+                       w, h, d_density, density_step);
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+extern "C" int rcflow_hsv_to_bgr_dev(rc_ctx* ctx, int stream, const float* d_hsv, size_t hsv_step, int w, int h,
+                                     float* d_bgr, size_t bgr_step) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    if (!d_hsv || !d_bgr || w <= 0 || h <= 0 || hsv_step < (size_t)w * 12 || bgr_step < (size_t)w * 12) return RC_EINVAL;
+    RC_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_hsv_to_bgr, dim3((w + 63) / 64, (h + 3) / 4), dim3(RC_BLOCK), 0, s->cur, d_hsv, hsv_step, w, h,
+                       d_bgr, bgr_step);
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+extern "C" int rcflow_analysis_size(rc_ctx* ctx, int stream, int* w, int* h) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !w || !h) return RC_EINVAL;
+    *w = s->an.w; *h = s->an.h;
+    return RC_OK;
+}

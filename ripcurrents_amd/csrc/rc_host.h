@@ -34,6 +34,7 @@ struct RcAnalysis {
     RcBuf pt;          // h*w float2 streamlines_mat
     RcBuf dist;        // h*w float streamlines_distance
     RcBuf scratch;     // reductions
+    RcBuf jet;         // COLORMAP_JET LUT (768 B) + the display maximum key
 };
 
 struct RcBatchKey {

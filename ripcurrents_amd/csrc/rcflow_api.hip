@@ -182,7 +182,7 @@ static void slot_free(RcSlot& s) {
     rc_buf_free(s.stage_u8); rc_buf_free(s.stage_flow); rc_buf_free(s.lk);
     for (auto& b : s.stage_f32) rc_buf_free(b);
     rc_buf_free(s.an.hist); rc_buf_free(s.an.hist_part); rc_buf_free(s.an.thr); rc_buf_free(s.an.acc);
-    rc_buf_free(s.an.pt); rc_buf_free(s.an.dist); rc_buf_free(s.an.scratch);
+    rc_buf_free(s.an.pt); rc_buf_free(s.an.dist); rc_buf_free(s.an.scratch); rc_buf_free(s.an.jet);
     if (s.own) (void)hipStreamDestroy(s.own);
     s.own = s.cur = nullptr;
 }

@@ -65,6 +65,20 @@ int main() {
         // from here both sides consume the GPU flow field, so everything must agree exactly
         pipe.streamline_field(2.f, 1);                                                       // ripcurrents.cpp:229-231
         orc_streamline_field(opt.data(), XDIM * 8, odist.data(), XDIM * 4, flow.data(), XDIM * 8, XDIM, YDIM, 2.f, 1, oUPPER);
+        if (framecount == 3) {                                                               // ripcurrents.cpp:233-257
+            std::vector<uint8_t> img((size_t)XDIM * YDIM * 3), oimg(img.size());
+            std::vector<float> spt((size_t)XDIM * YDIM * 2), sdist((size_t)XDIM * YDIM);
+            pipe.streamline_field_state((rc::Pixel2*)spt.data(), sdist.data());
+            rc::Mat mimg(YDIM, XDIM, 3, 1, img.data());
+            for (int which = 0; which < 3; which++) {
+                if (which == 0) pipe.streamline_displacement(mimg);
+                else if (which == 1) pipe.streamline_total_motion(mimg);
+                else pipe.streamline_ratio(mimg);
+                double mx;
+                orc_streamline_display(spt.data(), XDIM * 8, sdist.data(), XDIM * 4, XDIM, YDIM, which, oimg.data(), XDIM * 3, &mx);
+                REQUIRE(img == oimg);
+            }
+        }
         streak.run(pipe);
         orc_streakline_step(overts.data(), &on, 160.f, 120.f, flow.data(), XDIM * 8, XDIM, YDIM, 1.f, &ofc);
 

@@ -307,3 +307,28 @@ def test_resize_bgr_to_gray_exact(ctx, orc):
         f = rng.randint(0, 256, (sh, sw, 3)).astype(np.uint8)
         got = ctx.resize_bgr_to_gray(f, dw, dh).cpu().numpy()
         assert np.array_equal(got, orc.resize_bgr_to_gray(f, dw, dh)), (sw, sh, dw, dh)
+
+
+def test_display_path_matches_oracle(ctx, orc):
+    """streamline_displacement / _total_motion / _ratio / _positions and the float
+    HSV->BGR of the flow window, on the slot's streamline field (ripcurrents.cpp:233-273, :405)."""
+    w, h = 640, 480
+    ctx.analysis_reset(w, h)
+    for t in range(3):
+        ctx.streamline_field(_flow_field(w, h, 20 + t, scale=1.5), 2.0, 1, UPPER=100.0)
+    pt, dist = ctx.streamline_field_state(w, h)
+    assert np.array_equal(ctx.jet_lut(), orc.jet_lut())
+    for which in (0, 1, 2):
+        img, mx = ctx.streamline_display(which)
+        ref, rmx = orc.streamline_display(pt, dist, which)
+        assert np.float32(rmx) == np.float32(mx)
+        got = img.cpu().numpy()
+        # sqrtf / division are correctly rounded on both sides: the 8-bit index is the same integer
+        assert np.array_equal(got, ref), "which=%d: %d pixels differ" % (which, (got != ref).any(axis=2).sum())
+    assert np.array_equal(ctx.streamline_positions().cpu().numpy(), orc.streamline_positions(pt))
+    # the display image create_flow leaves in `current` (angle, 0.7|1, mag/UPPER2d) -> BGR
+    rng = np.random.RandomState(5)
+    hsv = np.stack([rng.uniform(0, 360, (h, w)), rng.choice([0.7, 1.0, 0.0], (h, w)), rng.uniform(0, 2, (h, w))],
+                   axis=2).astype(np.float32)
+    hsv[0, :8, 0] = (0, 60, 120, 180, 240, 300, 360, 359.99997)
+    assert np.array_equal(ctx.hsv_to_bgr(hsv).cpu().numpy(), orc.hsv_to_bgr(hsv))
