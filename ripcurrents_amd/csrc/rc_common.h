@@ -58,6 +58,7 @@ struct RcPyrArgs {
     int ksize;
     const float* kern;        // device, ksize floats
     int tw, th, reg_wp, reg_hmax;
+    int direct;               // diagnostic (ablate bit 12): the earlier per-pixel / LDS-staged kernels
 };
 
 struct RcPolyArgs {

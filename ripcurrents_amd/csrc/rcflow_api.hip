@@ -534,6 +534,7 @@ static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t fr
         pa.w = L.w; pa.h = L.h; pa.scale_x = L.scale_x; pa.scale_y = L.scale_y;
         pa.ksize = L.ksize; pa.kern = (const float*)s.kern.p + pl.kern_off[k];
         pa.tw = L.pyr_tw; pa.th = L.pyr_th; pa.reg_wp = L.pyr_reg_w; pa.reg_hmax = L.pyr_reg_h;
+        pa.direct = (ctx->ablate >> 12) & 1;
         {
             RcProfScope ps(ctx, s.cur, RC_K_PYR, k, (double)count * ((double)pl.w * pl.h + 4. * n));
             rc_launch_pyr(pa, count, L.pyr_lds, s.cur);
@@ -842,6 +843,7 @@ extern "C" int rcflow_stage_pyr_level_dev(rc_ctx* ctx, int stream, const uint8_t
     pa.w = L.w; pa.h = L.h; pa.scale_x = L.scale_x; pa.scale_y = L.scale_y;
     pa.ksize = L.ksize; pa.kern = (const float*)s->stage_f32[0].p;
     pa.tw = L.pyr_tw; pa.th = L.pyr_th; pa.reg_wp = L.pyr_reg_w; pa.reg_hmax = L.pyr_reg_h;
+    pa.direct = (ctx->ablate >> 12) & 1;
     rc_launch_pyr(pa, 1, L.pyr_lds, s->cur);
     RC_HIP(hipGetLastError());
     return RC_OK;

@@ -61,7 +61,8 @@ def main():
         r["analysis_GBs_of_57B_per_px"] = round(57 * n / t / 1e9, 1)
         if tag == "1080p":
             for name, p in (("main264_gauss_win3", dict(P, flags=256)), ("main1119_gauss_win10_it3", dict(P, winsize=10, iterations=3, flags=256)),
-                            ("main609_gauss_win20_it3", dict(P, winsize=20, iterations=3, flags=256))):
+                            ("main609_gauss_win20_it3", dict(P, winsize=20, iterations=3, flags=256)),
+                            ("android_box_win5_it3_4scales", dict(P, levels=3, winsize=5, iterations=3, flags=0))):
                 t = timeit(lambda: ctx.farneback_clip(frames, flows, **p), 3, 1) / (T - 1)
                 r[name + "_fps"] = round(1 / t, 1)
             host = frames[:2].cpu().numpy()

@@ -41,7 +41,8 @@ def _report(name, got, ref):
 
 
 @pytest.mark.parametrize("size,k", [((640, 480), 0), ((640, 480), 1), ((640, 480), 2), ((333, 251), 1),
-                                    ((1920, 1080), 2), ((97, 65), 0)])
+                                    ((1920, 1080), 2), ((97, 65), 0), ((1920, 1080), 3), ((1920, 1080), 4),
+                                    ((3840, 2160), 4), ((1000, 700), 3), ((333, 251), 2), ((2001, 1127), 1)])
 def test_pyr_level_bit_exact(ctx, orc, size, k):
     w, h = size
     img = synth.surf_clip(w, h, 1, seed=7)[0]
@@ -50,6 +51,13 @@ def test_pyr_level_bit_exact(ctx, orc, size, k):
     got = ctx.stage_pyr_level(img, 0.5, k).cpu().numpy()
     assert got.shape == ref.shape
     assert np.array_equal(got, ref), "max diff %g" % np.abs(got - ref).max()
+    # the earlier kernels (per-pixel direct form / LDS-staged region) stay selectable and agree
+    ctx.set_option("ablate", 4096)
+    try:
+        old = ctx.stage_pyr_level(img, 0.5, k).cpu().numpy()
+    finally:
+        ctx.set_option("ablate", 0)
+    assert np.array_equal(old, ref)
 
 
 def test_pyr_level_noninteger_scale(ctx, orc):
