@@ -187,11 +187,16 @@ __global__ __launch_bounds__(RC_BLOCK) void k_hist_fold(int* parts, int* words) 
 }
 
 // Threshold scans, ripcurrents_module.cpp:109-144, one lane per direction.
-__global__ void k_thresholds(const int* words, float* thr) {
-    const int* hist = words;
-    const int* hist2d = words + RC_HIST_BINS;
-    const int histsum = words[RC_HIST_BINS + RC_HIST_DIRECTIONS * RC_HIST_BINS];
-    const int* histsum2d = words + RC_HIST_BINS + RC_HIST_DIRECTIONS * RC_HIST_BINS + 1;
+__global__ __launch_bounds__(RC_BLOCK) void k_thresholds(const int* words, float* thr) {
+    // the 1887 counters are staged in LDS in one parallel sweep: the scans below are chains of
+    // dependent reads (a global round trip each would cost ~10 us for the kernel)
+    __shared__ int sw[RC_HIST_WORDS];
+    for (int i = threadIdx.x; i < RC_HIST_WORDS; i += RC_BLOCK) sw[i] = words[i];
+    __syncthreads();
+    const int* hist = sw;
+    const int* hist2d = sw + RC_HIST_BINS;
+    const int histsum = sw[RC_HIST_BINS + RC_HIST_DIRECTIONS * RC_HIST_BINS];
+    const int* histsum2d = sw + RC_HIST_BINS + RC_HIST_DIRECTIONS * RC_HIST_BINS + 1;
     __shared__ int s_target, s_threshsum;
     if (threadIdx.x == 0) {
         int threshsum = 0, bin = RC_HIST_BINS - 1;
@@ -672,7 +677,7 @@ extern "C" int rcflow_histogram_clip_dev(rc_ctx* ctx, int stream, const float* d
         int nb = grid_for(per_frame);
         // many light blocks (measured: 16384 total beat 2048 by 25 %): the partial tables keep
         // the flush chains short, and one ballot round catches the dominant bin of a wave
-        int cap = 16384 / count;
+        int cap = (ctx->hist_blocks > 0 ? ctx->hist_blocks : 16384) / count;
         if (cap < 8) cap = 8;
         if (nb > cap) nb = cap;
         hipLaunchKernelGGL(k_polar_hist<1>, dim3(nb, count), dim3(RC_BLOCK), 0, s->cur, d_flows, flow_frame_stride,
@@ -695,7 +700,7 @@ extern "C" int rcflow_thresholds_dev(rc_ctx* ctx, int stream) {
     RC_HIP(hipSetDevice(ctx->device));
     {
         RcProfScope ps(ctx, s->cur, RC_K_THRESH, 0, 4. * RC_HIST_WORDS);
-        hipLaunchKernelGGL(k_thresholds, dim3(1), dim3(64), 0, s->cur, (const int*)s->an.hist.p, (float*)s->an.thr.p);
+        hipLaunchKernelGGL(k_thresholds, dim3(1), dim3(RC_BLOCK), 0, s->cur, (const int*)s->an.hist.p, (float*)s->an.thr.p);
     }
     RC_HIP(hipGetLastError());
     return RC_OK;

@@ -316,6 +316,133 @@ __global__ __launch_bounds__(RC_BLOCK) void k_flow_iter(RcIterArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// Large windows (winsize 5 / 10 / 20: the Android fork, main.cpp:1119, main.cpp:609): 32x32 tile,
+// NT threads chosen so that the one to three blocks the LDS footprint allows still put 16 waves
+// on a CU.  Same three phases and the same operation order as k_flow_iter (bit-identical), but
+// the vertical pass walks each column with a register window (one LDS read per new row instead
+// of 2M+1 per output).
+template <int M_, int GAUSS_, int NT>
+__global__ __launch_bounds__(NT) void k_flow_iter_big(RcIterArgs a) {
+    constexpr int TW = 32, TH = 32, MW = TW + 2 * M_, MH = TH + 2 * M_, MP = MW | 1;
+    constexpr int CH = 8, NCH = TH / CH;                 // vertical pass: chunks of CH output rows
+    extern __shared__ __align__(16) float smf[];
+    float* Ms = smf;                    // [5][MH][MP]
+    float* Vs = smf + 5 * MH * MP;      // [5][TH][MP]
+    const int tid = threadIdx.x;
+    const int z = blockIdx.y;
+    const int t = a.xcd_remap ? rc_xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y) : (int)blockIdx.x;
+    const int tx0 = (t % a.tiles_x) * TW, ty0 = (t / a.tiles_x) * TH;
+    const int w = a.w, h = a.h;
+    const size_t s0 = (size_t)((a.slot0 + z * a.zstep) % a.nslots) * a.R_slot_stride;
+    const size_t s1 = (size_t)((a.slot1 + z * a.zstep) % a.nslots) * a.R_slot_stride;
+    const float4* RA0 = a.RA + s0;  const float* RB0 = a.RB + s0;
+    const float4* RA1 = a.RA + s1;  const float* RB1 = a.RB + s1;
+    const float2* fin = a.fin ? a.fin + (size_t)z * a.fin_pair_stride : nullptr;
+    char* fout = a.fout + (size_t)z * a.fout_pair_stride;
+
+    // ---- phase 1: matrices for tile + halo -> LDS
+    for (int base = tid; base < MW * MH; base += NT * RC_ITER_BATCH) {
+        float2 d[RC_ITER_BATCH];
+        int gxs[RC_ITER_BATCH], gys[RC_ITER_BATCH];
+#pragma unroll
+        for (int q = 0; q < RC_ITER_BATCH; q++) {
+            int idx = min(base + q * NT, MW * MH - 1);
+            int ly = idx / MW, lx = idx - ly * MW;
+            gxs[q] = rc_clampi(tx0 - M_ + lx, 0, w - 1);
+            gys[q] = rc_clampi(ty0 - M_ + ly, 0, h - 1);
+            d[q] = rc_flow_in(a, fin, gxs[q], gys[q]);
+        }
+        RcM5 v[RC_ITER_BATCH];
+#pragma unroll
+        for (int q = 0; q < RC_ITER_BATCH; q++)
+            v[q] = rc_matrices(RA0, RB0, RA1, RB1, gxs[q], gys[q], w, h, d[q].x, d[q].y);
+#pragma unroll
+        for (int q = 0; q < RC_ITER_BATCH; q++) {
+            int idx = base + q * NT;
+            if (idx < MW * MH) {
+                int ly = idx / MW, lx = idx - ly * MW;
+                float* mp = Ms + ly * MP + lx;
+                mp[0] = v[q].m0;
+                mp[MH * MP] = v[q].m1;
+                mp[2 * MH * MP] = v[q].m2;
+                mp[3 * MH * MP] = v[q].m3;
+                mp[4 * MH * MP] = v[q].m4;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: vertical pass, item = (plane, chunk of CH rows, column); lanes walk columns
+    for (int idx = tid; idx < 5 * NCH * MW; idx += NT) {
+        const int c = idx / (NCH * MW), rem = idx - c * (NCH * MW);
+        const int chunk = rem / MW, col = rem - chunk * MW;
+        const float* mc = Ms + c * MH * MP + (chunk * CH) * MP + col;
+        float v[CH + 2 * M_];
+#pragma unroll
+        for (int r = 0; r < CH + 2 * M_; r++) v[r] = mc[r * MP];
+        float* vo = Vs + c * TH * MP + (chunk * CH) * MP + col;
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            float s;
+            if (GAUSS_) {
+                s = v[j + M_] * a.win.k[0];
+#pragma unroll
+                for (int i = 1; i <= M_; i++) s += (v[j + M_ + i] + v[j + M_ - i]) * a.win.k[i];
+            } else {
+                s = v[j + M_];
+#pragma unroll
+                for (int i = 1; i <= M_; i++) s += v[j + M_ + i] + v[j + M_ - i];
+            }
+            vo[j * MP] = s;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: horizontal pass + solve
+    for (int idx = tid; idx < TW * TH; idx += NT) {
+        int o = idx / TW, lx = idx - o * TW;
+        int gx = tx0 + lx, gy = ty0 + o;
+        if (gx >= w || gy >= h) continue;
+        double g[5];
+        const float* vc = Vs + o * MP + lx + M_;
+        if (GAUSS_) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const float* v = vc + c * TH * MP;
+                float s = v[0] * a.win.k[0];
+#pragma unroll
+                for (int i = 1; i <= M_; i++) s += a.win.k[i] * (v[-i] + v[i]);
+                g[c] = s;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const float* v = vc + c * TH * MP;
+                double s = v[0];
+#pragma unroll
+                for (int i = 1; i <= M_; i++) s += (double)v[i] + (double)v[-i];
+                g[c] = s * a.win.box_scale;
+            }
+        }
+        *(float2*)(fout + (size_t)gy * a.fout_step + (size_t)gx * 8) = rc_solve(g);
+    }
+}
+
+template <int M, int G, int NT>
+static void launch_iter_big(RcIterArgs a, int pairs, hipStream_t s) {
+    constexpr int MW = 32 + 2 * M, MP = MW | 1;
+    const size_t lds = sizeof(float) * 5 * (size_t)MP * (MW + 32);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)k_flow_iter_big<M, G, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    a.tw = 32; a.th = 32;
+    a.tiles_x = (a.w + 31) / 32; a.tiles_y = (a.h + 31) / 32;
+    hipLaunchKernelGGL((k_flow_iter_big<M, G, NT>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(NT), lds, s, a);
+}
+
+// ------------------------------------------------------------------------------------
 // The 3x3-window kernel (winsize 3: ripcurrents.cpp:215, main.cpp:264): 64x16 tile,
 // 512 threads.  Latency is what bounds this stage, so the memory phases are explicit: every
 // thread first has the flow of its (at most three) tile+halo pixels in flight, then all
@@ -1085,6 +1212,12 @@ void rc_launch_flow_iter(const RcIterArgs& a, int pairs, hipStream_t s) {
         return;
     }
     if (m == 1) { g ? launch_iter_t<64, 16, 1, 1>(a, pairs, s) : launch_iter_t<64, 16, 1, 0>(a, pairs, s); return; }
+    if (a.solve && !(a.ablate & 8192)) {
+        // 16 waves per CU: LDS 50 KB (m = 2) -> 3 blocks x 512 threads, 64 KB (m = 5) -> 2 x 1024, 89 KB (m = 10) -> 1 x 1024
+        if (m == 2) { g ? launch_iter_big<2, 1, 512>(a, pairs, s) : launch_iter_big<2, 0, 512>(a, pairs, s); return; }
+        if (m == 5) { g ? launch_iter_big<5, 1, 1024>(a, pairs, s) : launch_iter_big<5, 0, 1024>(a, pairs, s); return; }
+        if (m == 10) { g ? launch_iter_big<10, 1, 1024>(a, pairs, s) : launch_iter_big<10, 0, 1024>(a, pairs, s); return; }
+    }
     if (m == 2) { g ? launch_iter_t<64, 16, 2, 1>(a, pairs, s) : launch_iter_t<64, 16, 2, 0>(a, pairs, s); return; }
     if (m == 5) { g ? launch_iter_t<32, 32, 5, 1>(a, pairs, s) : launch_iter_t<32, 32, 5, 0>(a, pairs, s); return; }
     if (m == 10) { g ? launch_iter_t<32, 32, 10, 1>(a, pairs, s) : launch_iter_t<32, 32, 10, 0>(a, pairs, s); return; }

@@ -368,7 +368,8 @@ void rc_launch_pyr(const RcPyrArgs& a, int frames, size_t lds, hipStream_t s) {
     const size_t rows_lds = ((size_t)ceil(8 * a.scale_y) + a.ksize + 3) * 32 * sizeof(float2);
     if (!a.direct && rows_lds <= 64 * 1024) {
         switch (a.ksize) {
-            case 9:       // (3 taps at decimation 2: the per-pixel direct form below is 20 % faster) launch_pyr_rows<4>(a, frames, s); return;
+            // (3 taps at decimation 2: the per-pixel direct form below is 20 % faster)
+            case 9: launch_pyr_rows<4>(a, frames, s); return;
             case 19: launch_pyr_rows<9>(a, frames, s); return;
             case 39: launch_pyr_rows<19>(a, frames, s); return;
             default: break;

@@ -76,6 +76,7 @@ struct rc_ctx {
     int fuse_iters = 1;
     int xcd_remap = 1;
     int poly_tile_h = 32;
+    int hist_blocks = 0;       // option "hist_blocks": cap on histogram blocks per launch (0 = default)
     int ablate = 0;
     void* stamps = nullptr;
     int prof_on = 0;

@@ -239,6 +239,9 @@ extern "C" int rcflow_set_option(rc_ctx* ctx, const char* name, int value) {
         ctx->fuse_iters = value ? 1 : 0;
     } else if (!strcmp(name, "xcd_remap")) {
         ctx->xcd_remap = value ? 1 : 0;
+    } else if (!strcmp(name, "hist_blocks")) {
+        if (value < 0 || value > 65535) return RC_EINVAL;
+        ctx->hist_blocks = value;
     } else if (!strcmp(name, "poly_tile_h")) {
         if (value != 32 && value != 48) return RC_EINVAL;
         ctx->poly_tile_h = value;

@@ -23,7 +23,9 @@ show(ctx, 32, "4K 5 scales (per frame)")
 ctx.close(); del frames, flows; torch.cuda.empty_cache()
 W, H = 1920, 1080
 ctx = Context(W, H)
-f0 = torch.from_numpy(synth.surf_field(W, H)).to(dev) if hasattr(synth, "surf_field") else torch.randn((H, W, 2), device=dev)
+import numpy as np
+U, V = synth.surf_field(W, H)
+f0 = torch.from_numpy(np.stack([U, V], axis=2).astype(np.float32)).to(dev)
 ctx.analysis_reset(W, H)
 def frame_analysis():
     ctx.streamline_field(f0, 2.0, 1)
