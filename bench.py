@@ -85,10 +85,18 @@ def main():
         if world == 1 and args.gpus > 1:
             print("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus, file=sys.stderr)
             sys.exit(2)
+    # RC_REHEARSE_GLOO=1: rehearsal of the N>1 path on a one-GPU box (every rank on cuda:0, gloo
+    # transport); never set by the driver
+    rehearse = os.environ.get("RC_REHEARSE_GLOO") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from ripcurrents_amd import synth
     from ripcurrents_amd.api import Context
@@ -110,9 +118,11 @@ def main():
         ctx.farneback_clip(frames, flows, **params)
         ctx.histogram_accumulate_clip(flows)
         if world > 1:
-            # global flow histogram: integer sum over RCCL, order independent
-            allreduce_hist_words(hist_words)
-        ctx.thresholds()
+            # global flow histogram: integer sum over RCCL, order independent; every
+            # rank then derives the same global thresholds from the same integers
+            ctx.thresholds_from_words(allreduce_hist_words(hist_words))
+        else:
+            ctx.thresholds()
 
     for _ in range(args.warmup):
         step()

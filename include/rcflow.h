@@ -158,6 +158,9 @@ int rcflow_histogram_clip_dev(rc_ctx* ctx, int stream, const float* d_flows_xy,
 /* Replaces the threshold scans of create_histogram (ripcurrents_module.cpp:109-144):
  * derives UPPER, UPPER2d[36], prop_above_upper[36] on the device from the slot's counts. */
 int rcflow_thresholds_dev(rc_ctx* ctx, int stream);
+/* the same scans on a caller-held block of RC_HIST_WORDS device counters (the all-reduced global
+ * histogram); the slot's own cumulative counters are not touched */
+int rcflow_thresholds_words_dev(rc_ctx* ctx, int stream, const int32_t* d_words);
 /* Copies the slot's histogram words (RC_HIST_WORDS int32: hist, hist2d, histsum,
  * histsum2d) and thresholds to the host; any pointer may be NULL.  Synchronises. */
 int rcflow_histogram_read(rc_ctx* ctx, int stream, int32_t* hist, int32_t* hist2d,

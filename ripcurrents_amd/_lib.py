@@ -59,6 +59,7 @@ SIGNATURES = {
     "rcflow_histogram_dev": [_vp, _i, _vp, _sz, _i, _i],
     "rcflow_histogram_clip_dev": [_vp, _i, _vp, _sz, _sz, _i, _i, _i],
     "rcflow_thresholds_dev": [_vp, _i],
+    "rcflow_thresholds_words_dev": [_vp, _i, _vp],
     "rcflow_histogram_read": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rcflow_histogram_write": [_vp, _i, _vp],
     "rcflow_histogram_device_ptr": [_vp, _i, C.POINTER(_vp)],

@@ -284,6 +284,15 @@ class Context:
         self._bind(stream)
         check(self._lib.rcflow_thresholds_dev(self._h, stream))
 
+    def thresholds_from_words(self, words, stream=0):
+        """UPPER / UPPER2d / prop_above_upper from a device block of histogram words (e.g. the
+        all-reduced global histogram); the slot's own counters stay as they are."""
+        wds = self._dev(words, torch.int32).contiguous()
+        if wds.numel() != HIST_WORDS:
+            raise ValueError("expected %d histogram words" % HIST_WORDS)
+        self._bind(stream)
+        check(self._lib.rcflow_thresholds_words_dev(self._h, stream, self._ptr(wds)))
+
     def histogram_read(self, st=None, stream=0):
         st = st or HistState()
         hs, up = C.c_int32(), C.c_float()

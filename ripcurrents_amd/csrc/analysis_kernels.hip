@@ -706,6 +706,21 @@ extern "C" int rcflow_thresholds_dev(rc_ctx* ctx, int stream) {
     return RC_OK;
 }
 
+// Thresholds from a caller-held block of counters (the all-reduced global histogram of SURVEY 8(e)):
+// the slot's own cumulative counters stay local, UPPER / UPPER2d / prop_above_upper become global.
+extern "C" int rcflow_thresholds_words_dev(rc_ctx* ctx, int stream, const int32_t* d_words) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !d_words) return RC_EINVAL;
+    if (!s->an.thr.p) { rc_set_error("no histogram state: call rcflow_analysis_reset first"); return RC_ESTATE; }
+    RC_HIP(hipSetDevice(ctx->device));
+    {
+        RcProfScope ps(ctx, s->cur, RC_K_THRESH, 0, 4. * RC_HIST_WORDS);
+        hipLaunchKernelGGL(k_thresholds, dim3(1), dim3(RC_BLOCK), 0, s->cur, (const int*)d_words, (float*)s->an.thr.p);
+    }
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
 extern "C" int rcflow_histogram_read(rc_ctx* ctx, int stream, int32_t* hist, int32_t* hist2d, int32_t* histsum,
                                      int32_t* histsum2d, float* UPPER, float* UPPER2d, float* prop) {
     RcSlot* s = rc_slot(ctx, stream);

@@ -332,3 +332,30 @@ def test_display_path_matches_oracle(ctx, orc):
                    axis=2).astype(np.float32)
     hsv[0, :8, 0] = (0, 60, 120, 180, 240, 300, 360, 359.99997)
     assert np.array_equal(ctx.hsv_to_bgr(hsv).cpu().numpy(), orc.hsv_to_bgr(hsv))
+
+
+def test_global_thresholds_from_reduced_words(ctx, orc):
+    """thresholds from the all-reduced counters of two segments equal the oracle's on
+    the summed histogram, and the slot's own counters stay local."""
+    import torch
+    w, h = 640, 480
+    words, sts = [], []
+    for seg in range(2):
+        ctx.analysis_reset(w, h)
+        ost = orc.HistState()
+        for t in range(2):
+            f = _flow_field(w, h, 40 + 10 * seg + t, scale=1.0 + seg)
+            ctx.histogram_accumulate(f)
+            orc.histogram_accumulate(orc.flow_to_polar(f), ost)
+        words.append(ctx.histogram_words().clone())
+        sts.append(ost)
+    total = words[0] + words[1]
+    g = orc.HistState()
+    g.hist = sts[0].hist + sts[1].hist; g.hist2d = sts[0].hist2d + sts[1].hist2d
+    g.histsum.value = sts[0].histsum.value + sts[1].histsum.value; g.histsum2d = sts[0].histsum2d + sts[1].histsum2d
+    orc.histogram_thresholds(g)
+    ctx.thresholds_from_words(total)
+    st = ctx.histogram_read()
+    assert st.UPPER == g.UPPER and np.array_equal(st.UPPER2d, g.UPPER2d)
+    assert np.array_equal(st.prop_above_upper, g.prop_above_upper, equal_nan=True)
+    assert torch.equal(ctx.histogram_words(), words[1])          # local counters untouched
