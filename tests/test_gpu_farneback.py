@@ -257,6 +257,37 @@ def test_4k_five_scales_properties(ctx):
     assert float((ex < 1e-2).float().mean()) > 0.99 and float((ey < 1e-2).float().mean()) > 0.99
 
 
+def test_4k_config3_advection_on_gpu_flow(ctx, orc):
+    """BASELINE config 3's second half: 250 seed streamlines (ripcurrents.cpp:170-172, :283-285) and 5
+    streaklines (main.cpp:118) advected through the 4K flow field the GPU produced -- the sampler is
+    the reference's own arithmetic, so positions must match the oracle bit for bit on that field."""
+    from ripcurrents_amd.api import Streakline
+    p = dict(RC215, levels=4)
+    w, h = 3840, 2160
+    clip = torch.as_tensor(synth.surf_clip(w, h, 3, seed=9)).cuda()
+    rng = np.random.RandomState(1)
+    seeds = np.stack([rng.uniform(0, w, 250), rng.uniform(0, h, 250)], axis=1).astype(np.float32)
+    ref_seeds = seeds.copy()
+    gens = [(w * (0.2 + 0.15 * i), h * 0.5) for i in range(5)]
+    sls = [Streakline(g) for g in gens]
+    overts = [np.zeros((8, 2), np.float32) for _ in gens]
+    state = [[1, 1] for _ in gens]
+    for i, g in enumerate(gens):
+        overts[i][0] = g
+    for t in range(2):
+        flow = ctx.calcOpticalFlowFarneback(clip[t], clip[t + 1], None, **p)
+        hflow = flow.cpu().numpy()
+        moved, _ = ctx.streamline(seeds, flow, 2.0, 1, 100.0, variant=3)
+        seeds = moved.cpu().numpy()
+        orc.streamline_points(ref_seeds, hflow, 2.0, 1, 100.0, variant=3)
+        assert np.array_equal(seeds, ref_seeds)
+        for i, sl in enumerate(sls):
+            sl.run(ctx, flow, w, h)
+            state[i] = list(orc.streakline_step(overts[i], state[i][0], gens[i], hflow, 1.0, state[i][1]))
+            assert sl.numberOfVertices == state[i][0] and sl.frameCount == state[i][1]
+            assert np.array_equal(np.asarray(sl.vertices, np.float32), overts[i][:state[i][0]])
+
+
 def test_error_codes(ctx):
     from ripcurrents_amd import RcflowError
     a = np.zeros((64, 64), np.uint8)
