@@ -11,6 +11,7 @@
 //   streamline_field           ripcurrents.hpp:22   ripcurrents_module.cpp:608-648
 //   streamline                 ripcurrents.hpp:23   ripcurrents_module.cpp:486-528
 //   Streakline                 Streakline.hpp:8-20  Streakline.cpp:11-71
+//   Timeline, PopulationMap    ripcurrents.hpp:64-75, 86-95  ripcurrents_module.cpp:751-807, 1140-1196
 // rc::Mat is a non-owning view with cv::Mat's fields (data, step, rows, cols); with OpenCV
 // present, include/rcflow_cv.hpp converts cv::Mat to it.  Errors are thrown as
 // rc::Error (the reference's OpenCV calls throw cv::Exception and are never caught).
@@ -284,6 +285,47 @@ class Streakline {
         vertices.insert(vertices.begin(), generationPoint);
         numberOfVertices = (int)vertices.size();
         frameCount++;
+    }
+};
+
+// Timeline (ripcurrents.hpp:64-75, ripcurrents_module.cpp:751-807) and PopulationMap
+// (ripcurrents.hpp:86-95, ripcurrents_module.cpp:1140-1196): point sets moved by sparse PyrLK with the
+// parameters of :775 / :1162; every vertex takes its tracked position.  Drawing stays with the caller.
+class Timeline {
+  public:
+    std::vector<Pixel2> vertices;
+    Timeline(Pixel2 lineStart, Pixel2 lineEnd, int numberOfVertices) {
+        float diffX = (lineEnd.x - lineStart.x) / numberOfVertices, diffY = (lineEnd.y - lineStart.y) / numberOfVertices;
+        for (int i = 0; i <= numberOfVertices; i++) vertices.push_back(Pixel2{lineStart.x + diffX * i, lineStart.y + diffY * i});
+    }
+    void runLK(Pipeline& pipe, const Mat& u_prev, const Mat& u_current) {
+        std::vector<Pixel2> next;
+        std::vector<unsigned char> status;
+        std::vector<float> err;
+        pipe.calcOpticalFlowPyrLK(u_prev, u_current, vertices, next, status, err, 50, 50, 3, 3, 30, 0.1, 10, 1e-4);
+        vertices = next;
+    }
+};
+
+class PopulationMap {
+  public:
+    std::vector<Pixel2> vertices;
+    // `unit_random` returns u in [0, 1] (the reference calls sranddev(); rand() / RAND_MAX); the
+    // reference's formula start + (end - start) * (u + 1) is kept as written.
+    template <class Rng>
+    PopulationMap(Pixel2 rectStart, Pixel2 rectEnd, int numberOfVertices, Rng&& unit_random) {
+        for (int i = 0; i < numberOfVertices; i++) {
+            float randX = (float)((rectEnd.x - rectStart.x) * ((double)unit_random() + 1) + rectStart.x);
+            float randY = (float)((rectEnd.y - rectStart.y) * ((double)unit_random() + 1) + rectStart.y);
+            vertices.push_back(Pixel2{randX, randY});
+        }
+    }
+    void runLK(Pipeline& pipe, const Mat& u_prev, const Mat& u_current) {
+        std::vector<Pixel2> next;
+        std::vector<unsigned char> status;
+        std::vector<float> err;
+        pipe.calcOpticalFlowPyrLK(u_prev, u_current, vertices, next, status, err, 50, 50, 3, 3, 30, 0.1, 10, 1e-4);
+        vertices = next;
     }
 };
 

@@ -23,7 +23,7 @@ import torch
 from . import _lib
 from ._lib import FarnebackParams, HIST_BINS, HIST_DIRECTIONS, HIST_WORDS, check
 
-__all__ = ["Context", "FarnebackParams", "Streakline", "HistState"]
+__all__ = ["Context", "FarnebackParams", "Streakline", "Timeline", "PopulationMap", "HistState"]
 
 
 def _params(pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags):
@@ -609,4 +609,48 @@ class Streakline:
         self.vertices = [self.generationPoint] + [tuple(map(float, p)) for p in nxt]
         self.numberOfVertices = len(self.vertices)
         self.frameCount += 1
+        return self.vertices
+
+
+def _run_lk_all(ctx, vertices, u_prev, u_current, stream=0):
+    """The PyrLK call shared by Timeline::runLK and PopulationMap::runLK (ripcurrents_module.cpp:775,
+    :1162): 50x50 window, maxLevel 3, COUNT+EPS (30, 0.1), flags 10, minEigThreshold 1e-4; every vertex
+    takes its tracked position (the jump rejection is commented out in the reference)."""
+    v = np.asarray(vertices, np.float32).reshape(-1, 2)
+    q, _, _ = ctx.calcOpticalFlowPyrLK(u_prev, u_current, v, win=(50, 50), max_level=3, crit_type=3, max_count=30,
+                                       epsilon=0.1, flags=10, min_eig_threshold=1e-4, stream=stream)
+    return [tuple(map(float, p)) for p in q.cpu().numpy()]
+
+
+class Timeline:
+    """Timeline (ripcurrents.hpp:64-75, ripcurrents_module.cpp:751-807): numberOfVertices + 1 points on
+    the segment lineStart..lineEnd, moved by sparse PyrLK every frame; drawing stays with the caller."""
+
+    def __init__(self, lineStart, lineEnd, numberOfVertices):
+        diffX = np.float32(np.float32(lineEnd[0] - lineStart[0]) / np.float32(numberOfVertices))
+        diffY = np.float32(np.float32(lineEnd[1] - lineStart[1]) / np.float32(numberOfVertices))
+        self.vertices = [(float(np.float32(lineStart[0]) + diffX * np.float32(i)),
+                          float(np.float32(lineStart[1]) + diffY * np.float32(i))) for i in range(numberOfVertices + 1)]
+
+    def runLK(self, ctx, u_prev, u_current, stream=0):
+        self.vertices = _run_lk_all(ctx, self.vertices, u_prev, u_current, stream)
+        return self.vertices
+
+
+class PopulationMap:
+    """PopulationMap (ripcurrents.hpp:86-95, ripcurrents_module.cpp:1140-1196): random points
+    rectStart + (rectEnd - rectStart) * (u + 1), u uniform in [0, 1] -- the reference's formula,
+    which lands them in the rectangle mirrored beyond rectEnd (`rand()/RAND_MAX + 1`) -- moved by
+    sparse PyrLK.  `rng` replaces the reference's sranddev()/rand() (not reproducible by design)."""
+
+    def __init__(self, rectStart, rectEnd, numberOfVertices, rng=None):
+        rng = rng or np.random.RandomState()
+        self.vertices = []
+        for _ in range(numberOfVertices):
+            randX = np.float32((rectEnd[0] - rectStart[0]) * (rng.uniform(0.0, 1.0) + 1) + rectStart[0])
+            randY = np.float32((rectEnd[1] - rectStart[1]) * (rng.uniform(0.0, 1.0) + 1) + rectStart[1])
+            self.vertices.append((float(randX), float(randY)))
+
+    def runLK(self, ctx, u_prev, u_current, stream=0):
+        self.vertices = _run_lk_all(ctx, self.vertices, u_prev, u_current, stream)
         return self.vertices

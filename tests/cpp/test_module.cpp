@@ -48,6 +48,8 @@ int main() {
     std::vector<float> lkverts(2 * 64, 0.f);
     lkverts[0] = 200.f; lkverts[1] = 90.f;
     int lkn = 1, lkfc = 1;
+    rc::Timeline timeline(rc::Pixel2{60.f, 60.f}, rc::Pixel2{260.f, 180.f}, 10);
+    REQUIRE(timeline.vertices.size() == 11);
 
     for (int framecount = 1; framecount <= 4; framecount++) {
         make_frame(f1, framecount);
@@ -58,6 +60,7 @@ int main() {
         for (size_t i = 0; i < flow.size(); i += 2)
             good += std::fabs(flow[i] - oflow[i]) <= 1e-3f && std::fabs(flow[i + 1] - oflow[i + 1]) <= 1e-3f;
         REQUIRE(good >= (size_t)(0.99 * XDIM * YDIM));
+        timeline.runLK(pipe, prev, next);                                                    // ripcurrents_module.cpp:765-807
         lkstreak.runLK(pipe, prev, next);                                                    // Streakline.cpp:22-71
         REQUIRE(orc_streakline_step_lk(lkverts.data(), &lkn, 200.f, 90.f, f2.data(), XDIM, f1.data(), XDIM, XDIM, YDIM, &lkfc) == 0);
         f2 = f1;                                                                             // u_f1.copyTo(u_f2)
@@ -105,6 +108,7 @@ int main() {
     pipe.streamline_field_state(pt.data(), dist.data());
     for (size_t i = 0; i < dist.size(); i++) REQUIRE(pt[i].x == opt[2 * i] && pt[i].y == opt[2 * i + 1] && dist[i] == odist[i]);
     REQUIRE(streak.numberOfVertices == on && streak.frameCount == ofc);
+    REQUIRE(timeline.vertices.size() == 11 && timeline.vertices[0].x != 60.f);     // every vertex was tracked
     REQUIRE(lkstreak.numberOfVertices == lkn && lkstreak.frameCount == lkfc);
     for (int i = 0; i < lkn; i++)      // exact window sums (GPU) vs raster-order float sums (oracle): ~1e-4 px
         REQUIRE(std::fabs(lkstreak.vertices[i].x - lkverts[2 * i]) < 5e-3f && std::fabs(lkstreak.vertices[i].y - lkverts[2 * i + 1]) < 5e-3f);

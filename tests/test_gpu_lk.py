@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from ripcurrents_amd import synth
-from ripcurrents_amd.api import Streakline
+from ripcurrents_amd.api import PopulationMap, Streakline, Timeline
 
 pytestmark = pytest.mark.gpu
 
@@ -97,3 +97,20 @@ def test_streakline_runlk_matches_oracle(ctx, orc):
         assert sl.numberOfVertices == n and sl.frameCount == fc
         got = np.asarray(sl.vertices, np.float32)
         assert np.abs(got - verts[:n]).max() < 5e-3
+
+
+def test_timeline_and_population_map(ctx, orc):
+    """Timeline / PopulationMap (ripcurrents_module.cpp:751-807, :1140-1196): constructors as written
+    in the reference, vertices moved by the PyrLK call of :775 / :1162 without jump rejection."""
+    w, h = 640, 480
+    fr = synth.surf_clip(w, h, 4)
+    tl = Timeline((100.0, 100.0), (500.0, 300.0), 8)
+    assert len(tl.vertices) == 9 and tl.vertices[0] == (100.0, 100.0) and tl.vertices[8] == (500.0, 300.0)
+    pm = PopulationMap((50.0, 60.0), (150.0, 160.0), 12, rng=np.random.RandomState(3))
+    assert all(150.0 <= x <= 250.0 and 160.0 <= y <= 260.0 for x, y in pm.vertices)   # the (u + 1) factor
+    for obj in (tl, pm):
+        ref = np.asarray(obj.vertices, np.float32)
+        for t in range(3):
+            obj.runLK(ctx, fr[t], fr[t + 1])
+            ref, _, _ = orc.pyrlk(fr[t], fr[t + 1], ref, win=(50, 50), max_level=3, epsilon=0.1, flags=10)
+            assert np.abs(np.asarray(obj.vertices, np.float32) - ref).max() < 5e-3
