@@ -397,7 +397,9 @@ void rc_launch_pyr(const RcPyrArgs& a, int frames, size_t lds, hipStream_t s) {
 // REFLECT_101; the resize is the identity) into the tile load, so the full-resolution
 // float image never exists in HBM.
 #define RC_POLY_BLOCK 512
-template <int R, int U8, int TH>
+typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int R, int U8, int TH, int MFMA>
 __global__ __launch_bounds__(RC_POLY_BLOCK) void k_polyexp(RcPolyArgs a) {
     constexpr int TW = 64, RP = (R + 3) & ~3;
     constexpr int INW = TW + 2 * RP, INH = TH + 2 * R;
@@ -551,6 +553,63 @@ __global__ __launch_bounds__(RC_POLY_BLOCK) void k_polyexp(RcPolyArgs a) {
     }
     __syncthreads();
 
+    if constexpr (MFMA) {
+        // ---- vertical pass on the matrix cores: Out(16 x 16) = T(16 x K) x In(K x 16) per wave, T the
+        // banded Toeplitz matrix of a vertical filter (K = 16 + 2R rows in, rounded up to 4s).
+        // v_mfma_f32_16x16x4_f32 is an exact f32 fmaf chain in k order, runs beside the VALU
+        // (which is what bounds this kernel) and takes the 6 filter x plane products
+        //   b1 = g.h0  b3 = xg.h0  b5 = xxg.h0 | b2 = g.h1  b6 = xg.h1 | b4 = g.h2.
+        // Lane l holds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; D: row 4 (l >> 4) + r, col l & 15.
+        static_assert(TH == 32, "8 waves = 2 x 4 sub-tiles of 16 x 16");
+        constexpr int KS = (16 + 2 * R + 3) / 4;
+        float* wt = hs + 3 * INH * TW;                  // [3][2R+1] taps by offset -R..R: g, xg (odd), xxg
+        if (tid < 3 * (2 * R + 1)) {
+            const int f3 = tid / (2 * R + 1), t = tid - f3 * (2 * R + 1), k = t < R ? R - t : t - R;
+            wt[tid] = f3 == 0 ? a.pk.g[k] : (f3 == 1 ? (t < R ? -a.pk.xg[k] : (t == R ? 0.f : a.pk.xg[k])) : a.pk.xxg[k]);
+        }
+        __syncthreads();
+        const int lane = tid & 63, wv = tid >> 6;
+        const int i = lane & 15, kk = lane >> 4;
+        const int y0 = 16 * (wv >> 2), x0 = 16 * (wv & 3);
+        rc_f32x4 c1 = {0, 0, 0, 0}, c2 = c1, c3 = c1, c4 = c1, c5 = c1, c6 = c1;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const int t = 4 * s + kk - i;               // tap index of A[i][4s + kk]
+            const bool on = (unsigned)t <= (unsigned)(2 * R);
+            const float wg = on ? wt[t] : 0.f, wx = on ? wt[2 * R + 1 + t] : 0.f, wq = on ? wt[2 * (2 * R + 1) + t] : 0.f;
+            const int row = min(y0 + 4 * s + kk, INH - 1);          // rows past the band have zero weight
+            const float* bp = hs + row * TW + x0 + i;
+            const float p0 = bp[0], p1 = bp[INH * TW], p2 = bp[2 * INH * TW];
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wg, p0, c1, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(wx, p0, c3, 0, 0, 0);
+            c5 = __builtin_amdgcn_mfma_f32_16x16x4f32(wq, p0, c5, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wg, p1, c2, 0, 0, 0);
+            c6 = __builtin_amdgcn_mfma_f32_16x16x4f32(wx, p1, c6, 0, 0, 0);
+            c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(wg, p2, c4, 0, 0, 0);
+        }
+        const int gx = tx0 + x0 + i;
+        if (gx < w) {
+            float4* RA = a.RA + (size_t)slot * a.R_slot_stride;
+            float* RB = a.RB + (size_t)slot * a.R_slot_stride;
+            const double dck = (double)dc * a.pk.kdc;
+            const float ig11f = (float)a.pk.ig11, ig55f = (float)a.pk.ig55;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int gy = ty0 + y0 + 4 * kk + r;
+                if (gy < h) {
+                    float4 ra;
+                    ra.x = c3[r] * ig11f;
+                    ra.y = c2[r] * ig11f;
+                    ra.z = (float)((double)c1[r] * a.pk.ig03 + (double)c5[r] * a.pk.ig33 + dck);
+                    ra.w = (float)((double)c1[r] * a.pk.ig03 + (double)c4[r] * a.pk.ig33 + dck);
+                    size_t p = (size_t)gy * w + gx;
+                    RA[p] = ra;
+                    RB[p] = c6[r] * ig55f;
+                }
+            }
+        }
+        return;
+    }
     // vertical pass: lane = column, NR output rows per thread
     constexpr int NR = TH / (RC_POLY_BLOCK / 64);
     static_assert(NR * (RC_POLY_BLOCK / 64) == TH, "tile height must be a multiple of 8");
@@ -624,28 +683,29 @@ __global__ __launch_bounds__(RC_POLY_BLOCK) void k_polyexp(RcPolyArgs a) {
     }
 }
 
-template <int R, int U8, int TH>
+template <int R, int U8, int TH, int MFMA>
 static void launch_polyexp_th(const RcPolyArgs& a, int frames, hipStream_t s) {
     constexpr int RP = (R + 3) & ~3;
     constexpr int INW = 64 + 2 * RP, INH = TH + 2 * R;
-    constexpr size_t lds_hs = sizeof(float) * 3 * (size_t)INH * 64, lds_ub = (size_t)(INH + 2) * (INW + 8);
+    constexpr size_t lds_hs = sizeof(float) * (3 * (size_t)INH * 64 + 3 * (2 * R + 1)), lds_ub = (size_t)(INH + 2) * (INW + 8);
     constexpr size_t lds = sizeof(float) * (size_t)INH * INW + (lds_hs > lds_ub ? lds_hs : lds_ub);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_polyexp<R, U8, TH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)k_polyexp<R, U8, TH, MFMA>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_set = true;
     }
     dim3 grid((a.w + 63) / 64, (a.h + TH - 1) / TH, frames);
-    hipLaunchKernelGGL((k_polyexp<R, U8, TH>), grid, dim3(RC_POLY_BLOCK), lds, s, a);
+    hipLaunchKernelGGL((k_polyexp<R, U8, TH, MFMA>), grid, dim3(RC_POLY_BLOCK), lds, s, a);
 }
 
 template <int R, int U8>
 static void launch_polyexp_t(const RcPolyArgs& a, int frames, hipStream_t s) {
     if constexpr (R <= 9) {
-        if (a.tile_h == 48) { launch_polyexp_th<R, U8, 48>(a, frames, s); return; }
+        if (a.tile_h == 48) { launch_polyexp_th<R, U8, 48, 0>(a, frames, s); return; }
     }
-    launch_polyexp_th<R, U8, 32>(a, frames, s);
+    if (a.valu_vertical) launch_polyexp_th<R, U8, 32, 0>(a, frames, s);
+    else launch_polyexp_th<R, U8, 32, 1>(a, frames, s);
 }
 
 template <int U8>

@@ -73,6 +73,7 @@ struct RcPolyArgs {
     int w, h;
     int tile_h;               // rows per block: 32 or 48 (option "poly_tile_h")
     int no_fast_u8;           // diagnostic: byte-wise staging for every tile
+    int valu_vertical;        // option "poly_mfma" = 0: vertical pass on the VALU instead of the matrix cores
     RcPolyK pk;
 };
 

@@ -76,6 +76,7 @@ struct rc_ctx {
     int fuse_iters = 1;
     int xcd_remap = 1;
     int poly_tile_h = 32;
+    int poly_mfma = 0;          // option "poly_mfma": vertical pass of the expansion on the matrix cores (measured 25 % slower)
     int hist_blocks = 0;       // option "hist_blocks": cap on histogram blocks per launch (0 = default)
     int ablate = 0;
     void* stamps = nullptr;

@@ -242,6 +242,8 @@ extern "C" int rcflow_set_option(rc_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "hist_blocks")) {
         if (value < 0 || value > 65535) return RC_EINVAL;
         ctx->hist_blocks = value;
+    } else if (!strcmp(name, "poly_mfma")) {
+        ctx->poly_mfma = value ? 1 : 0;
     } else if (!strcmp(name, "poly_tile_h")) {
         if (value != 32 && value != 48) return RC_EINVAL;
         ctx->poly_tile_h = value;
@@ -520,7 +522,7 @@ static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t fr
         memset(&qa, 0, sizeof(qa));
         qa.RA = (float4*)s.RA[k].p; qa.RB = (float*)s.RB[k].p; qa.R_slot_stride = n;
         qa.slot0 = dslot0; qa.nslots = pl.nslots; qa.zstep = zstep; qa.w = L.w; qa.h = L.h; qa.pk = pl.pk;
-        qa.tile_h = ctx->poly_tile_h; qa.no_fast_u8 = (ctx->ablate >> 11) & 1;
+        qa.tile_h = ctx->poly_tile_h; qa.no_fast_u8 = (ctx->ablate >> 11) & 1; qa.valu_vertical = !ctx->poly_mfma;
         if (k == 0) {
             // scale 0: pyramid (3x3 blur, identity resize) fused into the expansion
             qa.src8 = d_src; qa.src8_step = step; qa.src8_frame_stride = frame_stride;
@@ -865,7 +867,7 @@ extern "C" int rcflow_stage_polyexp_dev(rc_ctx* ctx, int stream, const float* d_
     memset(&qa, 0, sizeof(qa));
     qa.I = d_I; qa.I_slot_stride = 0;
     qa.RA = (float4*)s->stage_f32[0].p; qa.RB = (float*)s->stage_f32[1].p; qa.R_slot_stride = 0;
-    qa.slot0 = 0; qa.nslots = 1; qa.zstep = 1; qa.w = w; qa.h = h; qa.tile_h = ctx->poly_tile_h;
+    qa.slot0 = 0; qa.nslots = 1; qa.zstep = 1; qa.w = w; qa.h = h; qa.tile_h = ctx->poly_tile_h; qa.valu_vertical = !ctx->poly_mfma;
     if ((rc = host_prepare_poly(poly_n, poly_sigma, ctx->exact_taps, qa.pk))) return rc;
     rc_launch_polyexp(qa, 1, s->cur);
     rc_launch_unpack_R5(qa.RA, qa.RB, d_R5, (int)n, s->cur);

@@ -85,6 +85,21 @@ def test_polyexp(ctx, orc, size, n, sigma):
     assert err.max() <= 2e-4
 
 
+def test_polyexp_matrix_core_vertical_pass(ctx, orc):
+    """Option poly_mfma: the vertical pass as a banded Toeplitz product on v_mfma_f32_16x16x4_f32
+    (exact f32 fma chain).  Same tolerance as the VALU form; it is off by default because it measured
+    25 % slower (the band wastes half of every 16 x 32 operand)."""
+    w, h = 640, 480
+    I = (synth.surf_clip(w, h, 1, seed=2)[0].astype(np.float32)) * 0.7 + 3.0
+    ref = orc.polyexp(I, 15, 1.2)
+    ctx.set_option("poly_mfma", 1)
+    try:
+        got = ctx.stage_polyexp(I, 15, 1.2).cpu().numpy()
+    finally:
+        ctx.set_option("poly_mfma", 0)
+    assert np.abs(got - ref).max() <= 2e-4
+
+
 def test_polyexp_exact_taps_option(ctx, orc):
     """Dropping the negligible taps (default) vs evaluating all 31 moves R by < 1e-5."""
     img = synth.surf_clip(320, 240, 1, seed=5)[0]
