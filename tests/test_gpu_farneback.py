@@ -176,6 +176,28 @@ def test_end_to_end_parity(ctx, orc, name, p, size, minfrac):
     assert st["p50"] <= 1e-4
 
 
+@pytest.mark.parametrize("size", [(32, 32), (33, 47), (64, 33), (100, 37), (130, 70), (257, 129), (31, 64), (1, 1), (2, 200)])
+def test_ragged_and_tiny_sizes(ctx, orc, size):
+    """Edge sizes (every kernel's border path, level cropping at min_size = 32, images smaller than a
+    tile / a window): same answers as the oracle, for every kernel family."""
+    w, h = size
+    clip = synth.surf_clip(max(w, 8), max(h, 8), 2, seed=17)[:, :h, :w].copy()
+    for p, minfrac in ((RC215, 0.97), (MAIN264, 0.80), (dict(RC215, levels=5, iterations=3), 0.97),
+                       (dict(RC215, winsize=7, iterations=1), 0.97), (AND167, 0.97), (MAIN1119, 0.97)):
+        ref = _oracle_flow(orc, clip[0], clip[1], p)
+        got = np.asarray(ctx.calcOpticalFlowFarneback(clip[0], clip[1], None, **p))
+        assert got.shape == ref.shape and np.isfinite(got).all()
+        err = np.abs(got - ref).max(-1)
+        frac = (err <= 1e-3).mean()
+        # images of a few thousand pixels are mostly border band (scaled matrices, replicate windows):
+        # fp32-vs-fp64 rounding is amplified there, so the share within 1e-3 is lower and a 2e-2 cap is added
+        bar = minfrac - (0.06 if w * h < 5000 else 0.0)
+        # (the sigma = 0.3 window of main.cpp:264 is a near-pointwise solve: chaotic where the matrix is
+        #  ill-conditioned, see DESIGN.md section 5 -- no cap there)
+        cap_ok = p is MAIN264 or np.percentile(err, 99) <= 2e-2
+        assert frac >= bar and cap_ok, (size, p, frac, float(err.max()))
+
+
 def test_device_entry_point_matches_host_entry_point(ctx):
     clip = synth.surf_clip(320, 240, 2, seed=9)
     a = ctx.calcOpticalFlowFarneback(clip[0], clip[1], None, **RC215)
