@@ -359,3 +359,48 @@ def test_global_thresholds_from_reduced_words(ctx, orc):
     assert st.UPPER == g.UPPER and np.array_equal(st.UPPER2d, g.UPPER2d)
     assert np.array_equal(st.prop_above_upper, g.prop_above_upper, equal_nan=True)
     assert torch.equal(ctx.histogram_words(), words[1])          # local counters untouched
+
+
+@pytest.mark.parametrize("size", [(1, 1), (2, 3), (33, 47), (130, 70), (65, 1), (1, 77)])
+def test_analysis_rows_on_ragged_and_tiny_sizes(ctx, orc, size):
+    """Every per-pixel analysis row on frames smaller than a block / with one row or column."""
+    w, h = size
+    rng = np.random.RandomState(w * 131 + h)
+    f = (rng.randn(h, w, 2) * 0.8).astype(np.float32)
+    ctx.analysis_reset(w, h)
+    st, ost = HistState(), orc.HistState()
+    ctx.create_histogram(f, st)
+    polar = orc.flow_to_polar(f)
+    orc.create_histogram(polar, ost)
+    assert np.array_equal(st.hist2d, ost.hist2d) and st.histsum == ost.histsum.value
+    assert st.UPPER == ost.UPPER and np.array_equal(st.prop_above_upper, ost.prop_above_upper, equal_nan=True)
+    outs = ctx.create_flow_accumulate(f, 40)
+    wc = np.zeros((h, w, 3), np.float32); acc2 = np.zeros((h, w, 3), np.float32)
+    orc.create_flow(polar, wc, acc2, ost.UPPER, 0.5, 0.2, ost.UPPER2d)
+    acc = np.zeros((h, w, 3), np.float32); out = np.zeros((h, w, 3), np.float32); mask = np.zeros((h, w), np.uint8)
+    orc.create_accumulationbuffer(acc, acc2, out, mask, 40)
+    assert np.array_equal(outs["waterclass"].cpu().numpy(), wc) and np.array_equal(outs["outmask"].cpu().numpy(), mask)
+    assert np.array_equal(ctx.create_edges(mask).cpu().numpy(), orc.create_edges(mask))
+    pt = np.zeros((h, w, 2), np.float32); dist = np.zeros((h, w), np.float32)
+    for _ in range(2):
+        ctx.streamline_field(f, 2.0, 1, UPPER=100.0)
+        orc.streamline_field(pt, dist, f, 2.0, 1, 100.0)
+    gpt, gdist = ctx.streamline_field_state(w, h)
+    assert np.array_equal(gpt, pt) and np.array_equal(gdist, dist)
+    for which in (0, 1, 2):
+        img, mx = ctx.streamline_display(which)
+        ref, rmx = orc.streamline_display(pt, dist, which)
+        assert np.array_equal(img.cpu().numpy(), ref)
+    assert np.array_equal(ctx.streamline_positions().cpu().numpy(), orc.streamline_positions(pt))
+    seeds = np.stack([rng.uniform(-2, w + 2, 9), rng.uniform(-2, h + 2, 9)], axis=1).astype(np.float32)
+    ref_seeds = seeds.copy()
+    moved, _ = ctx.streamline(seeds, f, 2.0, 3, 100.0, variant=3)
+    orc.streamline_points(ref_seeds, f, 2.0, 3, 100.0, variant=3)
+    assert np.array_equal(moved.cpu().numpy(), ref_seeds)
+    og = f.copy(); orc.subtract_average(og)
+    assert np.abs(ctx.subtructAverage(f.copy()).cpu().numpy() - og).max() <= 2.4e-7 * max(1.0, np.abs(og).max())
+    og = f.copy(); orc.stabilizer(og)
+    got = ctx.stabilizer(f.copy()).cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(og))          # 0/0 patch means on 1-pixel frames, as in the reference
+    ok = ~np.isnan(og)
+    assert np.abs(got[ok] - og[ok]).max(initial=0.0) <= 2.4e-7 * max(1.0, np.abs(og[ok]).max(initial=0.0))
