@@ -45,6 +45,7 @@ struct RcBatchKey {
 
 struct RcSlot {
     hipStream_t own = nullptr, cur = nullptr;
+    hipStream_t aux = nullptr;  // second stream of the clip path (expansions beside flow kernels)
     RcPlan plan;
     RcBuf kern;
     RcBuf I[RC_MAX_LEVELS], RA[RC_MAX_LEVELS], RB[RC_MAX_LEVELS];
@@ -76,6 +77,7 @@ struct rc_ctx {
     int fuse_iters = 1;
     int xcd_remap = 1;
     int poly_tile_h = 32;
+    int overlap = 0;           // option "overlap": clip path on two streams (measured: no gain, the grids fill the GPU)
     int poly_mfma = 0;          // option "poly_mfma": vertical pass of the expansion on the matrix cores (measured 25 % slower)
     int hist_blocks = 0;       // option "hist_blocks": cap on histogram blocks per launch (0 = default)
     int ablate = 0;

@@ -184,6 +184,8 @@ static void slot_free(RcSlot& s) {
     rc_buf_free(s.an.hist); rc_buf_free(s.an.hist_part); rc_buf_free(s.an.thr); rc_buf_free(s.an.acc);
     rc_buf_free(s.an.pt); rc_buf_free(s.an.dist); rc_buf_free(s.an.scratch); rc_buf_free(s.an.jet);
     if (s.own) (void)hipStreamDestroy(s.own);
+    if (s.aux) (void)hipStreamDestroy(s.aux);
+    s.aux = nullptr;
     s.own = s.cur = nullptr;
 }
 
@@ -242,6 +244,8 @@ extern "C" int rcflow_set_option(rc_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "hist_blocks")) {
         if (value < 0 || value > 65535) return RC_EINVAL;
         ctx->hist_blocks = value;
+    } else if (!strcmp(name, "overlap")) {
+        ctx->overlap = value ? 1 : 0;
     } else if (!strcmp(name, "poly_mfma")) {
         ctx->poly_mfma = value ? 1 : 0;
     } else if (!strcmp(name, "poly_tile_h")) {
@@ -717,25 +721,68 @@ extern "C" int rcflow_farneback_clip_dev(rc_ctx* ctx, int stream, const uint8_t*
         return RC_EINVAL;
     }
     RC_HIP(hipSetDevice(ctx->device));
-    int rc = ensure_plan(ctx, *s, w, h, p, ctx->chunk);
+    // Two chunks of expansions in the ring when the clip spans several chunks: the expansions of
+    // chunk c+1 (VALU-bound) then run on a second stream beside the flow kernels of chunk c
+    // (bound by the memory system), joined by events.  Results do not depend on it.
+    const bool overlap = ctx->overlap && nframes - 1 > ctx->chunk;
+    int rc = ensure_plan(ctx, *s, w, h, p, ctx->chunk, overlap ? 2 * ctx->chunk + 1 : 0);
     if (rc) return rc;
     s->primed = 0;
     s->batch_primed = 0;
     const int C = s->plan.chunk, ns = s->plan.nslots;
     int s0 = 0;
-    if ((rc = expand_frames(ctx, *s, d_frames, frame_stride, step, 1, 0))) return rc;
-    for (int t = 0; t < nframes - 1;) {
+    if (!overlap) {
+        if ((rc = expand_frames(ctx, *s, d_frames, frame_stride, step, 1, 0))) return rc;
+        for (int t = 0; t < nframes - 1;) {
+            int np = nframes - 1 - t < C ? nframes - 1 - t : C;
+            if ((rc = expand_frames(ctx, *s, d_frames + (size_t)(t + 1) * frame_stride, frame_stride, step, np,
+                                    (s0 + 1) % ns)))
+                return rc;
+            if ((rc = compute_flows(ctx, *s, np, s0, (float*)((char*)d_flows + (size_t)t * flow_frame_stride),
+                                    flow_frame_stride, flow_step)))
+                return rc;
+            s0 = (s0 + np) % ns;
+            t += np;
+        }
+        return RC_OK;
+    }
+    if (!s->aux) RC_HIP(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
+    hipStream_t flow_stream = s->cur, exp_stream = s->aux;
+    std::vector<hipEvent_t> evs;
+    auto new_event = [&](hipStream_t st) -> hipEvent_t {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        (void)hipEventRecord(e, st);
+        evs.push_back(e);
+        return e;
+    };
+    auto cleanup = [&]() { for (hipEvent_t e : evs) (void)hipEventDestroy(e); };   // destruction is deferred by the runtime
+    hipEvent_t fork = new_event(flow_stream);               // everything the caller queued so far (the frames)
+    if (!fork) { rc_set_error("hipEventCreate failed"); return RC_EHIP; }
+    (void)hipStreamWaitEvent(exp_stream, fork, 0);
+    hipEvent_t flows_done[2] = {nullptr, nullptr};          // flows of chunk c-1, c-2 (their slots get reused)
+    s->cur = exp_stream;
+    rc = expand_frames(ctx, *s, d_frames, frame_stride, step, 1, 0);
+    s->cur = flow_stream;
+    for (int t = 0, c = 0; rc == RC_OK && t < nframes - 1; c++) {
         int np = nframes - 1 - t < C ? nframes - 1 - t : C;
-        if ((rc = expand_frames(ctx, *s, d_frames + (size_t)(t + 1) * frame_stride, frame_stride, step, np,
-                                (s0 + 1) % ns)))
-            return rc;
-        if ((rc = compute_flows(ctx, *s, np, s0, (float*)((char*)d_flows + (size_t)t * flow_frame_stride),
-                                flow_frame_stride, flow_step)))
-            return rc;
+        if (flows_done[c & 1]) (void)hipStreamWaitEvent(exp_stream, flows_done[c & 1], 0);     // chunk c-2 released its slots
+        s->cur = exp_stream;
+        rc = expand_frames(ctx, *s, d_frames + (size_t)(t + 1) * frame_stride, frame_stride, step, np, (s0 + 1) % ns);
+        s->cur = flow_stream;
+        if (rc) break;
+        hipEvent_t expanded = new_event(exp_stream);
+        if (!expanded) { rc = RC_EHIP; break; }
+        (void)hipStreamWaitEvent(flow_stream, expanded, 0);
+        rc = compute_flows(ctx, *s, np, s0, (float*)((char*)d_flows + (size_t)t * flow_frame_stride), flow_frame_stride,
+                           flow_step);
+        if (rc) break;
+        if (!(flows_done[c & 1] = new_event(flow_stream))) { rc = RC_EHIP; break; }
         s0 = (s0 + np) % ns;
         t += np;
     }
-    return RC_OK;
+    cleanup();
+    return rc;
 }
 
 // ---------------------------------------------------------------------------- lockstep batch of streams
