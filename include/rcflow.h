@@ -84,7 +84,14 @@ int rcflow_use_own_stream(rc_ctx* ctx, int stream);
  * "exact_taps" = 1 keeps every polynomial-expansion tap instead of dropping taps whose
  * total weight is below 1e-8 of the kernel mass (default 0);
  * "fuse_iters" = 0 runs every Farneback iteration as its own launch instead of two per
- * launch (default 1; results are bit-identical either way). */
+ * launch (default 1; results are bit-identical either way).
+ * Measurement switches, all speed-only except where noted: "xcd_remap" (1) XCD-aware tile order;
+ * "poly_tile_h" (32 | 48) rows per expansion block -- changes the per-tile DC and with it the last
+ * bits of R; "poly_mfma" (0) vertical pass of the expansion on the matrix cores -- different
+ * summation order, same tolerance; "overlap" (0) clip path on two streams; "hist_blocks" (0 = default)
+ * cap on histogram blocks; "ablate" bit field selecting earlier kernel forms for A/B runs
+ * (64 LDS-resident flow kernel, 128 / 256 other flow tiles, 2048 byte-wise u8 staging, 4096 earlier
+ * pyramid kernels, 8192 earlier large-window kernel); "stamps" diagnostic builds only. */
 int rcflow_set_option(rc_ctx* ctx, const char* name, int value);
 
 /* ------------------------------------------------------------------ A: Farneback
