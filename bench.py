@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket every kernel of every Nth timed step with HIP events (1 = every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roof", action="store_true", help="skip the measured memory roof (read/fill/copy microbench)")
     ap.add_argument("--cpu-pairs", type=int, default=6)
     ap.add_argument("--gaussian", action="store_true", help="main.cpp:264 variant (flags=256)")
     args = ap.parse_args()
@@ -153,6 +154,12 @@ def main():
     if events:
         ctx.profile_enable(False)
         prof = ctx.profile_read()
+    roof = None
+    if rank == 0 and not args.no_roof:
+        try:
+            roof = ctx.measure_memory_roof(1 << 30)
+        except Exception:
+            roof = None
 
     if rank == 0:
         frames_done = world * args.pairs * args.steps
@@ -191,6 +198,10 @@ def main():
                                               "note": "inputs once + outputs once of the kernel as built "
                                                       "(M never materialised, two iterations per launch)"},
                                "share_of_gpu_time": round(dom["total_ms"] / tot, 3)}
+            if roof:
+                # also against the roof this device actually reaches (streaming kernels, 1 GiB)
+                out["roofline"]["peak_measured"] = {k: round(v, 1) for k, v in roof.items()}
+                out["roofline"]["compulsory"]["frac_of_measured_read"] = round(own / roof["read"], 4)
             out["kernels"] = [{"kernel": p["kernel"], "launches": p["launches"],
                                "avg_us": round(1e3 * p["total_ms"] / p["launches"], 2),
                                "GBs_model": round(p["model_bytes"] / (p["total_ms"] * 1e-3) / 1e9, 1),

@@ -285,6 +285,12 @@ int rcflow_profile_reset(rc_ctx* ctx);
 int rcflow_profile_read(rc_ctx* ctx, int cap, const char** names, int* launches,
                         double* total_ms, double* alg_bytes, double* model_bytes);
 
+/* The memory roof this device actually reaches: streaming read, fill and copy
+ * (read + write bytes) in GB/s over scratch buffers of `bytes` (use >= 1 GiB: beyond the Infinity
+ * Cache).  Blocks; allocates and frees 2 x bytes. */
+int rcflow_measure_memory_roof(rc_ctx* ctx, int stream, size_t bytes, double* read_GBs, double* write_GBs,
+                               double* copy_GBs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,7 @@ SIGNATURES = {
     "rcflow_pyrlk_dev": [_vp, _i, _vp, _sz, _vp, _sz, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _d],
     "rcflow_pyrlk_u8": [_vp, _i, _vp, _sz, _vp, _sz, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _d],
     "rcflow_pyrlk_levels": [_i, _i, _i, _i, _i],
+    "rcflow_measure_memory_roof": [_vp, _i, _sz, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)],
     "rcflow_profile_enable": [_vp, _i],
     "rcflow_profile_reset": [_vp],
     "rcflow_profile_read": [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i), C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)],

@@ -542,6 +542,13 @@ class Context:
         return check(self._lib.rcflow_pyrlk_levels(w, h, int(win[0]), int(win[1]), int(max_level)))
 
     # ------------------------------------------------------------------ measurement
+    def measure_memory_roof(self, nbytes=1 << 30, stream=0):
+        """Streaming read / fill / copy GB/s this device reaches (SURVEY 8(d) measured peak)."""
+        r, w, c = C.c_double(0), C.c_double(0), C.c_double(0)
+        self._bind(stream)
+        check(self._lib.rcflow_measure_memory_roof(self._h, stream, nbytes, C.byref(r), C.byref(w), C.byref(c)))
+        return {"read": r.value, "write": w.value, "copy": c.value}
+
     def profile_enable(self, on=True):
         check(self._lib.rcflow_profile_enable(self._h, 1 if on else 0))
 
