@@ -90,7 +90,7 @@ int rcflow_use_own_stream(rc_ctx* ctx, int stream);
  * bits of R; "poly_mfma" (0) vertical pass of the expansion on the matrix cores -- different
  * summation order, same tolerance; "overlap" (0) clip path on two streams; "hist_blocks" (0 = default)
  * cap on histogram blocks; "ablate" bit field selecting earlier kernel forms for A/B runs
- * (64 LDS-resident flow kernel, 128 / 256 other flow tiles, 2048 byte-wise u8 staging, 4096 earlier
+ * (64 LDS-resident flow kernel, 128 / 256 / 512 other flow tiles, 2048 byte-wise u8 staging, 4096 earlier
  * pyramid kernels, 8192 earlier large-window kernel); "stamps" diagnostic builds only. */
 int rcflow_set_option(rc_ctx* ctx, const char* name, int value);
 

@@ -938,15 +938,15 @@ __device__ __forceinline__ void rc_hpair_dpp(float (&s)[5], const float (&V)[5])
         : "v"(V[0]), "v"(V[1]), "v"(V[2]), "v"(V[3]), "v"(V[4]), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(t4));
 }
 
-template <int GAUSS_, int NIT>
+template <int GAUSS_, int NIT, int MW>
 __device__ __forceinline__ void rc_rr_flows(const float (&m)[NIT][5], const float* XR, int grp, int x,
                                             const RcWindow& win, float2 (&f)[NIT]) {
     const int gu = max(grp - 1, 0), gd = min(grp + 1, 7);
     float up[5], dn[5];
 #pragma unroll
     for (int c = 0; c < 5; c++) {
-        up[c] = XR[((gu * 2 + 1) * 5 + c) * 32 + x];
-        dn[c] = XR[((gd * 2 + 0) * 5 + c) * 32 + x];
+        up[c] = XR[((gu * 2 + 1) * 5 + c) * MW + x];
+        dn[c] = XR[((gd * 2 + 0) * 5 + c) * MW + x];
     }
     float V[NIT][5];
 #pragma unroll
@@ -972,18 +972,18 @@ __device__ __forceinline__ void rc_rr_flows(const float (&m)[NIT][5], const floa
     }
 }
 
-template <int NIT>
+template <int NIT, int MW>
 __device__ __forceinline__ void rc_rr_exchange(const float (&m)[NIT][5], float* XR, int grp, int x) {
 #pragma unroll
     for (int c = 0; c < 5; c++) {
-        XR[((grp * 2 + 0) * 5 + c) * 32 + x] = m[0][c];
-        XR[((grp * 2 + 1) * 5 + c) * 32 + x] = m[NIT - 1][c];
+        XR[((grp * 2 + 0) * 5 + c) * MW + x] = m[0][c];
+        XR[((grp * 2 + 1) * 5 + c) * MW + x] = m[NIT - 1][c];
     }
 }
 
-template <int IN_MODE, int GAUSS_, int NIT, int D, int MINB>
-__global__ __launch_bounds__(256, MINB) void k_flow_iter2_rr(RcIterArgs a) {
-    constexpr int NT = 256, MW = 32, MH = 8 * NIT, TW = MW - 4, TH = MH - 4;
+template <int IN_MODE, int GAUSS_, int NIT, int D, int MINB, int MW>
+__global__ __launch_bounds__(8 * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
+    constexpr int NT = 8 * MW, MH = 8 * NIT, TW = MW - 4, TH = MH - 4;      // 8 groups of NIT rows, MW columns
     constexpr int WW = MW + 2 * D, WH = MH + 2 * D, WN = WW * WH, NWL = (WN + NT - 1) / NT;
     constexpr int WNP = (WN + 63) & ~63;    // whole waves of LDS-DMA
     constexpr int MP = MW + 1, PLANE = MH * MP;
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256, MINB) void k_flow_iter2_rr(RcIterArgs a) {
     extern __shared__ __align__(16) float smf[];
     float4* LA = (float4*)smf;              // [WH][WW]  R1 (y, x, yy, xx)
     float* LB = smf + 4 * WNP;              // [WH][WW]  R1 xy
-    float* XR = LB + WNP;                   // [8][2][5][32] first / last row of every group
+    float* XR = LB + WNP;                   // [8][2][5][MW] first / last row of every group
     float* Ms = smf;                        // border blocks only: [5][MH][MP], after the window is dead
     const int tid = threadIdx.x;
     const int z = blockIdx.y;
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(256, MINB) void k_flow_iter2_rr(RcIterArgs a) {
     char* fout = a.fout + (size_t)z * a.fout_pair_stride;
     const int ox = tx0 - 2 - D, oy = ty0 - 2 - D;             // window origin (image coordinates)
 
-    const int x = tid & 31, grp = tid >> 5, ly0 = grp * NIT;
+    const int x = tid & (MW - 1), grp = tid / MW, ly0 = grp * NIT;
     const int px = tx0 - 2 + x;
     const int gxo = rc_clampi(px, 0, w - 1);
     int gys[NIT];
@@ -1081,13 +1081,13 @@ __global__ __launch_bounds__(256, MINB) void k_flow_iter2_rr(RcIterArgs a) {
         RcM5 v = rc_matrices_reg(A0[q], B0[q], g, dx[q], dy[q], gxo, gys[q], w, h, !interior);
         m[q][0] = v.m0; m[q][1] = v.m1; m[q][2] = v.m2; m[q][3] = v.m3; m[q][4] = v.m4;
     }
-    rc_rr_exchange<NIT>(m, XR, grp, x);
+    rc_rr_exchange<NIT, MW>(m, XR, grp, x);
     __syncthreads();
 
     // ---- flow1 (meaningful on the grid minus its outer ring), then M1 in place of M0
     {
         float2 f1[NIT];
-        rc_rr_flows<GAUSS_, NIT>(m, XR, grp, x, a.win, f1);
+        rc_rr_flows<GAUSS_, NIT, MW>(m, XR, grp, x, a.win, f1);
 #pragma unroll
         for (int q = 0; q < NIT; q++) {
             RcGather g;
@@ -1115,13 +1115,13 @@ __global__ __launch_bounds__(256, MINB) void k_flow_iter2_rr(RcIterArgs a) {
             }
         }
     }
-    rc_rr_exchange<NIT>(m, XR, grp, x);
+    rc_rr_exchange<NIT, MW>(m, XR, grp, x);
     __syncthreads();
 
     // ---- flow2 on the tile
     {
         float2 f2[NIT];
-        rc_rr_flows<GAUSS_, NIT>(m, XR, grp, x, a.win, f2);
+        rc_rr_flows<GAUSS_, NIT, MW>(m, XR, grp, x, a.win, f2);
         if (x >= 2 && x < MW - 2 && px < w) {
 #pragma unroll
             for (int q = 0; q < NIT; q++) {
@@ -1133,14 +1133,19 @@ __global__ __launch_bounds__(256, MINB) void k_flow_iter2_rr(RcIterArgs a) {
     }
 }
 
-template <int IN_MODE, int G, int NIT, int D, int MINB>
+template <int IN_MODE, int G, int NIT, int D, int MINB, int MW = 32>
 static void launch_rr_t(RcIterArgs a, int pairs, hipStream_t s) {
-    constexpr int MW = 32, MH = 8 * NIT, TW = MW - 4, TH = MH - 4;
+    constexpr int MH = 8 * NIT, TW = MW - 4, TH = MH - 4;
     a.tw = TW; a.th = TH;
     a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
     constexpr int WN = (MW + 2 * D) * (MH + 2 * D), WNP = (WN + 63) & ~63;
-    size_t lds = sizeof(float) * (5 * WNP + 8 * 2 * 5 * 32);
-    hipLaunchKernelGGL((k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(256), lds, s, a);
+    size_t lds = sizeof(float) * (5 * WNP + 8 * 2 * 5 * MW);
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB, MW>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(8 * MW), lds, s, a);
 }
 
 template <int IN_MODE, int G>
@@ -1148,6 +1153,7 @@ static void launch_w3x2(RcIterArgs a, int pairs, hipStream_t s) {
     if (a.ablate & 64) launch_w3x2_t<IN_MODE, G, 32, 16, 256, 4>(a, pairs, s);   // LDS-resident M (first form)
     else if (a.ablate & 128) launch_rr_t<IN_MODE, G, 3, 4, 5>(a, pairs, s);     // 28x20 tile, 5 blocks per CU
     else if (a.ablate & 256) launch_rr_t<IN_MODE, G, 2, 4, 6>(a, pairs, s);     // 28x12 tile, 6 blocks per CU
+    else if (a.ablate & 512) launch_rr_t<IN_MODE, G, 4, 3, 2, 64>(a, pairs, s);  // 60x28 tile, 512 threads, 2 blocks per CU
     else launch_rr_t<IN_MODE, G, 4, 3, 4>(a, pairs, s);                         // 28x28 tile, 4 blocks per CU
 }
 
