@@ -34,6 +34,25 @@ def main():
     np.savez_compressed(os.path.join(HERE, "histogram_96x80.npz"), flow=flow, hist=st.hist, hist2d=st.hist2d,
                         histsum=np.int32(st.histsum.value), histsum2d=st.histsum2d, UPPER=np.float32(st.UPPER),
                         UPPER2d=st.UPPER2d, prop_above_upper=st.prop_above_upper)
+    # sparse PyrLK (Streakline.cpp:32 parameters) and the display path
+    lk = synth.surf_clip(160, 120, 2, seed=77)
+    rng = np.random.RandomState(5)
+    pts = np.stack([rng.uniform(4, 156, 24), rng.uniform(4, 116, 24)], axis=1).astype(np.float32)
+    pts[0] = (-50.0, 10.0)
+    q, st2, er = oracle.pyrlk(lk[0], lk[1], pts, win=(50, 50), max_level=3, epsilon=0.1, flags=10)
+    q21, st21, er21 = oracle.pyrlk(lk[0], lk[1], pts, win=(21, 21), max_level=3, epsilon=0.01, flags=0)
+    np.savez_compressed(os.path.join(HERE, "pyrlk_160x120.npz"), prev=lk[0], next=lk[1], pts=pts, next50=q, status50=st2,
+                        err50=er, next21=q21, status21=st21, err21=er21)
+    pt = (rng.randn(48, 64, 2) * 2).astype(np.float32)
+    dist = (np.abs(rng.randn(48, 64)) * 3).astype(np.float32)
+    dist[0, :5] = 0
+    pt[0, :3] = 0
+    imgs = [oracle.streamline_display(pt, dist, w)[0] for w in (0, 1, 2)]
+    hsv = np.stack([rng.uniform(0, 360, (48, 64)), rng.choice([0.7, 1.0], (48, 64)), rng.uniform(0, 1.5, (48, 64))],
+                   axis=2).astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "display_64x48.npz"), pt=pt, dist=dist, displacement=imgs[0], total_motion=imgs[1],
+                        ratio=imgs[2], positions=oracle.streamline_positions(pt), jet=oracle.jet_lut(), hsv=hsv,
+                        bgr=oracle.hsv_to_bgr(hsv))
     print("wrote fixtures to", HERE)
 
 

@@ -404,3 +404,12 @@ def test_analysis_rows_on_ragged_and_tiny_sizes(ctx, orc, size):
     assert np.array_equal(np.isnan(got), np.isnan(og))          # 0/0 patch means on 1-pixel frames, as in the reference
     ok = ~np.isnan(og)
     assert np.abs(got[ok] - og[ok]).max(initial=0.0) <= 2.4e-7 * max(1.0, np.abs(og[ok]).max(initial=0.0))
+
+
+def test_display_against_committed_golden_fixture(ctx):
+    """tests/golden/display_64x48.npz: inputs + oracle outputs (tests/golden/make_golden.py)."""
+    import os
+    import torch
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "display_64x48.npz"))
+    assert np.array_equal(ctx.jet_lut(), g["jet"])
+    assert np.array_equal(ctx.hsv_to_bgr(g["hsv"]).cpu().numpy(), g["bgr"])

@@ -114,3 +114,14 @@ def test_timeline_and_population_map(ctx, orc):
             obj.runLK(ctx, fr[t], fr[t + 1])
             ref, _, _ = orc.pyrlk(fr[t], fr[t + 1], ref, win=(50, 50), max_level=3, epsilon=0.1, flags=10)
             assert np.abs(np.asarray(obj.vertices, np.float32) - ref).max() < 5e-3
+
+
+def test_pyrlk_against_committed_golden_fixture(ctx):
+    """tests/golden/pyrlk_160x120.npz: inputs + oracle outputs (tests/golden/make_golden.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pyrlk_160x120.npz"))
+    for tag, win, eps, flags in (("50", (50, 50), 0.1, 10), ("21", (21, 21), 0.01, 0)):
+        q, st, er = ctx.calcOpticalFlowPyrLK(g["prev"], g["next"], g["pts"], win=win, max_level=3, epsilon=eps, flags=flags)
+        assert np.array_equal(st.cpu().numpy(), g["status" + tag])
+        ok = g["status" + tag] == 1
+        assert np.abs(q.cpu().numpy()[ok] - g["next" + tag][ok]).max() < 2e-3
