@@ -938,10 +938,10 @@ __device__ __forceinline__ void rc_hpair_dpp(float (&s)[5], const float (&V)[5])
         : "v"(V[0]), "v"(V[1]), "v"(V[2]), "v"(V[3]), "v"(V[4]), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(t4));
 }
 
-template <int GAUSS_, int NIT, int MW>
+template <int GAUSS_, int NIT, int MW, int NG>
 __device__ __forceinline__ void rc_rr_flows(const float (&m)[NIT][5], const float* XR, int grp, int x,
                                             const RcWindow& win, float2 (&f)[NIT]) {
-    const int gu = max(grp - 1, 0), gd = min(grp + 1, 7);
+    const int gu = max(grp - 1, 0), gd = min(grp + 1, NG - 1);
     float up[5], dn[5];
 #pragma unroll
     for (int c = 0; c < 5; c++) {
@@ -981,9 +981,9 @@ __device__ __forceinline__ void rc_rr_exchange(const float (&m)[NIT][5], float* 
     }
 }
 
-template <int IN_MODE, int GAUSS_, int NIT, int D, int MINB, int MW>
-__global__ __launch_bounds__(8 * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
-    constexpr int NT = 8 * MW, MH = 8 * NIT, TW = MW - 4, TH = MH - 4;      // 8 groups of NIT rows, MW columns
+template <int IN_MODE, int GAUSS_, int NIT, int D, int MINB, int MW, int NG>
+__global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
+    constexpr int NT = NG * MW, MH = NG * NIT, TW = MW - 4, TH = MH - 4;    // NG groups of NIT rows, MW columns
     constexpr int WW = MW + 2 * D, WH = MH + 2 * D, WN = WW * WH, NWL = (WN + NT - 1) / NT;
     constexpr int WNP = (WN + 63) & ~63;    // whole waves of LDS-DMA
     constexpr int MP = MW + 1, PLANE = MH * MP;
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(8 * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
     extern __shared__ __align__(16) float smf[];
     float4* LA = (float4*)smf;              // [WH][WW]  R1 (y, x, yy, xx)
     float* LB = smf + 4 * WNP;              // [WH][WW]  R1 xy
-    float* XR = LB + WNP;                   // [8][2][5][MW] first / last row of every group
+    float* XR = LB + WNP;                   // [NG][2][5][MW] first / last row of every group
     float* Ms = smf;                        // border blocks only: [5][MH][MP], after the window is dead
     const int tid = threadIdx.x;
     const int z = blockIdx.y;
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(8 * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
     // ---- flow1 (meaningful on the grid minus its outer ring), then M1 in place of M0
     {
         float2 f1[NIT];
-        rc_rr_flows<GAUSS_, NIT, MW>(m, XR, grp, x, a.win, f1);
+        rc_rr_flows<GAUSS_, NIT, MW, NG>(m, XR, grp, x, a.win, f1);
 #pragma unroll
         for (int q = 0; q < NIT; q++) {
             RcGather g;
@@ -1121,7 +1121,7 @@ __global__ __launch_bounds__(8 * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
     // ---- flow2 on the tile
     {
         float2 f2[NIT];
-        rc_rr_flows<GAUSS_, NIT, MW>(m, XR, grp, x, a.win, f2);
+        rc_rr_flows<GAUSS_, NIT, MW, NG>(m, XR, grp, x, a.win, f2);
         if (x >= 2 && x < MW - 2 && px < w) {
 #pragma unroll
             for (int q = 0; q < NIT; q++) {
@@ -1133,19 +1133,19 @@ __global__ __launch_bounds__(8 * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
     }
 }
 
-template <int IN_MODE, int G, int NIT, int D, int MINB, int MW = 32>
+template <int IN_MODE, int G, int NIT, int D, int MINB, int MW = 32, int NG = 8>
 static void launch_rr_t(RcIterArgs a, int pairs, hipStream_t s) {
-    constexpr int MH = 8 * NIT, TW = MW - 4, TH = MH - 4;
+    constexpr int MH = NG * NIT, TW = MW - 4, TH = MH - 4;
     a.tw = TW; a.th = TH;
     a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
     constexpr int WN = (MW + 2 * D) * (MH + 2 * D), WNP = (WN + 63) & ~63;
-    size_t lds = sizeof(float) * (5 * WNP + 8 * 2 * 5 * MW);
+    size_t lds = sizeof(float) * (5 * WNP + NG * 2 * 5 * MW);
     static bool attr = false;
     if (!attr && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void*)k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB, MW, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB, MW>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(8 * MW), lds, s, a);
+    hipLaunchKernelGGL((k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB, MW, NG>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(NG * MW), lds, s, a);
 }
 
 template <int IN_MODE, int G>
@@ -1154,6 +1154,8 @@ static void launch_w3x2(RcIterArgs a, int pairs, hipStream_t s) {
     else if (a.ablate & 128) launch_rr_t<IN_MODE, G, 3, 4, 5>(a, pairs, s);     // 28x20 tile, 5 blocks per CU
     else if (a.ablate & 256) launch_rr_t<IN_MODE, G, 2, 4, 6>(a, pairs, s);     // 28x12 tile, 6 blocks per CU
     else if (a.ablate & 512) launch_rr_t<IN_MODE, G, 4, 3, 2, 64>(a, pairs, s);  // 60x28 tile, 512 threads, 2 blocks per CU
+    else if (a.ablate & 1024) launch_rr_t<IN_MODE, G, 2, 3, 4, 32, 16>(a, pairs, s);  // 28x28 tile, 512 threads x 2 rows
+    else if (a.ablate & 16384) launch_rr_t<IN_MODE, G, 2, 3, 8, 32, 16>(a, pairs, s); // same, registers capped for 8 waves per SIMD
     else launch_rr_t<IN_MODE, G, 4, 3, 4>(a, pairs, s);                         // 28x28 tile, 4 blocks per CU
 }
 
