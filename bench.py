@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=32, help="frame pairs (flow fields) per step")
     ap.add_argument("--chunk", type=int, default=0, help="pairs per launch (0 = library default)")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--event-every", type=int, default=4,
+    ap.add_argument("--event-every", type=int, default=10,
                     help="bracket every kernel of every Nth timed step with HIP events (1 = every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roof", action="store_true", help="skip the measured memory roof (read/fill/copy microbench)")
