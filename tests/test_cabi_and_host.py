@@ -101,3 +101,13 @@ def test_segment_bounds_cover_the_clip():
                 a, b = segment_bounds(nframes, world, r)
                 pairs += [(t, t + 1) for t in range(a, b - 1)]
             assert pairs == [(t, t + 1) for t in range(nframes - 1)]
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/rcflow.h (and the oracle's header) compile as C99."""
+    src = tmp_path / "c99.c"
+    src.write_text('#include "rcflow.h"\n#include "rc_oracle.h"\nint main(void) { return RC_OK; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                        "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
