@@ -105,17 +105,22 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist(const float* flow0, siz
     // every lane runs the same number of rounds so the ballots see whole waves; four loads are in
     // flight per thread before the first is consumed
     const long long rounds = (total + span - 1) / span;
+    // (row, pair-in-row) of the thread's item, advanced by `span` items per round without a division
+    const long long i0 = (long long)blockIdx.x * RC_BLOCK + threadIdx.x;
+    int yy = (int)(i0 / w2), xx = (int)(i0 - (long long)yy * w2);
+    const int dy = (int)(span / w2), dx = (int)(span - (long long)dy * w2);
     constexpr int UNR = 4;
     for (long long it0 = 0; it0 < rounds; it0 += UNR) {
         float4 v[UNR];
         int nv[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
-            long long i = (it0 + u) * span + (long long)blockIdx.x * RC_BLOCK + threadIdx.x;
             nv[u] = 0;
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (it0 + u < rounds && i < total) {
-                int y = (int)(i / w2), x = (int)(i - (long long)y * w2) * 2;
+            const int y = yy, x = xx * 2;
+            yy += dy; xx += dx;
+            if (xx >= w2) { xx -= w2; yy++; }
+            if (it0 + u < rounds && y < h) {
                 const float2* r = rc_row2(flow, step, y) + x;
                 if (x + 1 < w && (((size_t)r) & 15) == 0) {
                     v[u] = *(const float4*)r;
