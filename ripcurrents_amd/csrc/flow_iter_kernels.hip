@@ -321,9 +321,9 @@ __global__ __launch_bounds__(RC_BLOCK) void k_flow_iter(RcIterArgs a) {
 // on a CU.  Same three phases and the same operation order as k_flow_iter (bit-identical), but
 // the vertical pass walks each column with a register window (one LDS read per new row instead
 // of 2M+1 per output).
-template <int M_, int GAUSS_, int NT>
+template <int M_, int GAUSS_, int NT, int TW>
 __global__ __launch_bounds__(NT) void k_flow_iter_big(RcIterArgs a) {
-    constexpr int TW = 32, TH = 32, MW = TW + 2 * M_, MH = TH + 2 * M_, MP = MW | 1;
+    constexpr int TH = 32, MW = TW + 2 * M_, MH = TH + 2 * M_, MP = MW | 1;
     constexpr int CH = 8, NCH = TH / CH;                 // vertical pass: chunks of CH output rows
     extern __shared__ __align__(16) float smf[];
     float* Ms = smf;                    // [5][MH][MP]
@@ -428,18 +428,18 @@ __global__ __launch_bounds__(NT) void k_flow_iter_big(RcIterArgs a) {
     }
 }
 
-template <int M, int G, int NT>
+template <int M, int G, int NT, int TW = 32>
 static void launch_iter_big(RcIterArgs a, int pairs, hipStream_t s) {
-    constexpr int MW = 32 + 2 * M, MP = MW | 1;
-    const size_t lds = sizeof(float) * 5 * (size_t)MP * (MW + 32);
+    constexpr int MW = TW + 2 * M, MH = 32 + 2 * M, MP = MW | 1;
+    const size_t lds = sizeof(float) * 5 * (size_t)MP * (MH + 32);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)k_flow_iter_big<M, G, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_flow_iter_big<M, G, NT, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    a.tw = 32; a.th = 32;
-    a.tiles_x = (a.w + 31) / 32; a.tiles_y = (a.h + 31) / 32;
-    hipLaunchKernelGGL((k_flow_iter_big<M, G, NT>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(NT), lds, s, a);
+    a.tw = TW; a.th = 32;
+    a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + 31) / 32;
+    hipLaunchKernelGGL((k_flow_iter_big<M, G, NT, TW>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(NT), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1221,10 +1221,14 @@ void rc_launch_flow_iter(const RcIterArgs& a, int pairs, hipStream_t s) {
     }
     if (m == 1) { g ? launch_iter_t<64, 16, 1, 1>(a, pairs, s) : launch_iter_t<64, 16, 1, 0>(a, pairs, s); return; }
     if (a.solve && !(a.ablate & 8192)) {
-        // 16 waves per CU: LDS 50 KB (m = 2) -> 3 blocks x 512 threads, 64 KB (m = 5) -> 2 x 1024, 89 KB (m = 10) -> 1 x 1024
+        // 16 waves per CU: LDS 50 KB (m = 2) -> 3 blocks x 512 threads, 64 KB (m = 5) -> 2 x 1024, 142 KB (m = 10, 64 x 32 tile) -> 1 x 1024
         if (m == 2) { g ? launch_iter_big<2, 1, 512>(a, pairs, s) : launch_iter_big<2, 0, 512>(a, pairs, s); return; }
-        if (m == 5) { g ? launch_iter_big<5, 1, 1024>(a, pairs, s) : launch_iter_big<5, 0, 1024>(a, pairs, s); return; }
-        if (m == 10) { g ? launch_iter_big<10, 1, 1024>(a, pairs, s) : launch_iter_big<10, 0, 1024>(a, pairs, s); return; }
+        if (m == 5) { g ? launch_iter_big<5, 1, 1024>(a, pairs, s) : launch_iter_big<5, 0, 1024>(a, pairs, s); return; }   // (64 wide: 6 % slower, one block per CU)
+        if (m == 10) {
+            if (a.ablate & 32768) { g ? launch_iter_big<10, 1, 1024>(a, pairs, s) : launch_iter_big<10, 0, 1024>(a, pairs, s); }
+            else { g ? launch_iter_big<10, 1, 1024, 64>(a, pairs, s) : launch_iter_big<10, 0, 1024, 64>(a, pairs, s); }
+            return;
+        }
     }
     if (m == 2) { g ? launch_iter_t<64, 16, 2, 1>(a, pairs, s) : launch_iter_t<64, 16, 2, 0>(a, pairs, s); return; }
     if (m == 5) { g ? launch_iter_t<32, 32, 5, 1>(a, pairs, s) : launch_iter_t<32, 32, 5, 0>(a, pairs, s); return; }

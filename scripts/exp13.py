@@ -14,7 +14,7 @@ for name, p in (("gauss win10 it3", dict(base, winsize=10, iterations=3, flags=2
                 ("box win5 it3 4 scales", dict(base, levels=3, winsize=5, iterations=3, flags=0)),
                 ("box win10 it3", dict(base, winsize=10, iterations=3, flags=0))):
     res = {}
-    for ab in (8192, 0, 8192, 0):
+    for ab in (8192, 0, 32768, 0, 32768):
         ctx.set_option("ablate", ab)
         for _ in range(2): ctx.farneback_clip(frames, flows, **p)
         torch.cuda.synchronize(); t = time.perf_counter()
@@ -24,4 +24,4 @@ for name, p in (("gauss win10 it3", dict(base, winsize=10, iterations=3, flags=2
         out = flows.cpu().numpy().copy()
         if ab == 8192: ref = out
         else: same = np.array_equal(out, ref)
-    print("%-24s old %.0f us  new %.0f us/frame (%.0f fps)  identical: %s" % (name, min(res[8192]), min(res[0]), 1e6 / min(res[0]), same), flush=True)
+    print("%-24s generic %.0f us  32x32 %.0f us  default %.0f us/frame (%.0f fps)  identical: %s" % (name, min(res[8192]), min(res[32768]), min(res[0]), 1e6 / min(res[0]), same), flush=True)
