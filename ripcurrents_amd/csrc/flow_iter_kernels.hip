@@ -1051,11 +1051,26 @@ __global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
     } else {
         float2 p00[NIT], p01[NIT], p10[NIT], p11[NIT];
         float ax, ay[NIT];
-        const int sx = rc_src_x(gxo, a.up_scale_x, a.fin_w, ax);
+        int sx, sys[NIT];
+        if (a.up_exact2) {
+            // exactly half-size coarse scale: (d + 0.5) * 0.5 - 0.5 = d/2 - 0.25 in closed form
+            // (floor = (d - 1) >> 1, fraction 0.75 for even d, 0.25 for odd d): same values as
+            // rc_src_x / rc_src_y without the double arithmetic
+            sx = (gxo - 1) >> 1;
+            ax = (gxo & 1) ? 0.25f : 0.75f;
+            if (sx < 0) { ax = 0.f; sx = 0; }
+            if (sx >= a.fin_w - 1) { ax = 0.f; sx = a.fin_w - 1; }
+#pragma unroll
+            for (int q = 0; q < NIT; q++) { sys[q] = (gys[q] - 1) >> 1; ay[q] = (gys[q] & 1) ? 0.25f : 0.75f; }
+        } else {
+            sx = rc_src_x(gxo, a.up_scale_x, a.fin_w, ax);
+#pragma unroll
+            for (int q = 0; q < NIT; q++) sys[q] = rc_src_y(gys[q], a.up_scale_y, ay[q]);
+        }
         const int sx1 = min(sx + 1, a.fin_w - 1);
 #pragma unroll
         for (int q = 0; q < NIT; q++) {
-            int sy = rc_src_y(gys[q], a.up_scale_y, ay[q]);
+            int sy = sys[q];
             int sy0 = rc_clampi(sy, 0, a.fin_h - 1), sy1 = rc_clampi(sy + 1, 0, a.fin_h - 1);
             const float2* S0 = fin + (size_t)sy0 * a.fin_w;
             const float2* S1 = fin + (size_t)sy1 * a.fin_w;

@@ -90,6 +90,7 @@ struct RcIterArgs {
     int fin_w, fin_h;
     double up_scale_x, up_scale_y;
     float up_mul;
+    int up_exact2;            // the coarse scale is exactly half-size (integer source coordinates, see k_flow_iter2_rr)
     // flow out
     char* fout;
     size_t fout_step;         // bytes per row

@@ -590,6 +590,7 @@ static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_
                     a.up_scale_x = 1. / ((double)L.w / cw);
                     a.up_scale_y = 1. / ((double)L.h / ch);
                     a.up_mul = (float)(1. / pl.prm.pyr_scale);
+                    a.up_exact2 = (L.w == 2 * cw && L.h == 2 * ch) ? 1 : 0;
                     in_bytes = 8. * cw * ch;
                 }
             } else {
