@@ -733,11 +733,13 @@ extern "C" int rcflow_farneback_clip_dev(rc_ctx* ctx, int stream, const uint8_t*
     const int C = s->plan.chunk, ns = s->plan.nslots;
     int s0 = 0;
     if (!overlap) {
-        if ((rc = expand_frames(ctx, *s, d_frames, frame_stride, step, 1, 0))) return rc;
         for (int t = 0; t < nframes - 1;) {
             int np = nframes - 1 - t < C ? nframes - 1 - t : C;
-            if ((rc = expand_frames(ctx, *s, d_frames + (size_t)(t + 1) * frame_stride, frame_stride, step, np,
-                                    (s0 + 1) % ns)))
+            // the first chunk expands its np + 1 frames in one launch (the ring holds chunk + 1 slots);
+            // later chunks reuse the last expansion of the previous one
+            if (t == 0) rc = expand_frames(ctx, *s, d_frames, frame_stride, step, np + 1, 0);
+            else rc = expand_frames(ctx, *s, d_frames + (size_t)(t + 1) * frame_stride, frame_stride, step, np, (s0 + 1) % ns);
+            if (rc)
                 return rc;
             if ((rc = compute_flows(ctx, *s, np, s0, (float*)((char*)d_flows + (size_t)t * flow_frame_stride),
                                     flow_frame_stride, flow_step)))
