@@ -52,7 +52,7 @@ def pmc_traffic(kernel, args):
     the launch shape differs from the profiled one."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        chunk = args.chunk or 16
+        chunk = args.chunk or 32
         if min(chunk, args.pairs) != d["pairs_per_launch"] or args.gaussian:
             return None
         return d["kernels"][kernel]["traffic_bytes_per_launch"]

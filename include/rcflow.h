@@ -80,7 +80,7 @@ int rcflow_sync(rc_ctx* ctx, int stream);
  * own non-blocking stream. */
 int rcflow_set_hip_stream(rc_ctx* ctx, int stream, void* hip_stream);
 int rcflow_use_own_stream(rc_ctx* ctx, int stream);
-/* Tunables: "chunk" = frame pairs per launch in clip mode (default 16);
+/* Tunables: "chunk" = frame pairs per launch in clip mode (default 32);
  * "exact_taps" = 1 keeps every polynomial-expansion tap instead of dropping taps whose
  * total weight is below 1e-8 of the kernel mass (default 0);
  * "fuse_iters" = 0 runs every Farneback iteration as its own launch instead of two per

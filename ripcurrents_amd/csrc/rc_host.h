@@ -72,7 +72,7 @@ struct rc_ctx {
     int device = 0;
     int max_w = 0, max_h = 0, nstreams = 0;
     RcSlot* slots = nullptr;
-    int chunk = 16;
+    int chunk = 32;
     int exact_taps = 0;
     int fuse_iters = 1;
     int xcd_remap = 1;

@@ -271,7 +271,7 @@ def test_two_stream_overlap_option_same_bits(ctx):
         b = out.cpu().numpy()
     finally:
         ctx.set_option("overlap", 0)
-        ctx.set_option("chunk", 16)
+        ctx.set_option("chunk", 32)
     assert np.array_equal(a, b)
 
 
@@ -282,7 +282,7 @@ def test_chunk_option_invariance(ctx):
         ctx.set_option("chunk", c)
         b = ctx.farneback_clip(clip, **RC215).cpu().numpy()
         assert np.array_equal(a, b)
-    ctx.set_option("chunk", 16)
+    ctx.set_option("chunk", 32)
 
 
 def test_full_size_1080p_parity(ctx, orc):
