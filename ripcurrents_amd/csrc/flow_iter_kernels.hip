@@ -432,11 +432,7 @@ template <int M, int G, int NT, int TW = 32>
 static void launch_iter_big(RcIterArgs a, int pairs, hipStream_t s) {
     constexpr int MW = TW + 2 * M, MH = 32 + 2 * M, MP = MW | 1;
     const size_t lds = sizeof(float) * 5 * (size_t)MP * (MH + 32);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)k_flow_iter_big<M, G, NT, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    RC_ALLOW_LDS((k_flow_iter_big<M, G, NT, TW>), lds);
     a.tw = TW; a.th = 32;
     a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + 31) / 32;
     hipLaunchKernelGGL((k_flow_iter_big<M, G, NT, TW>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(NT), lds, s, a);
@@ -1155,11 +1151,7 @@ static void launch_rr_t(RcIterArgs a, int pairs, hipStream_t s) {
     a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
     constexpr int WN = (MW + 2 * D) * (MH + 2 * D), WNP = (WN + 63) & ~63;
     size_t lds = sizeof(float) * (5 * WNP + NG * 2 * 5 * MW);
-    static bool attr = false;
-    if (!attr && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void*)k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB, MW, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    RC_ALLOW_LDS((k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB, MW, NG>), lds);
     hipLaunchKernelGGL((k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB, MW, NG>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(NG * MW), lds, s, a);
 }
 
@@ -1196,11 +1188,7 @@ static size_t iter_lds(int tw, int th, int m, bool two_buffers) {
 template <int TW, int TH, int M, int G>
 static void launch_iter_t(RcIterArgs a, int pairs, hipStream_t s) {
     size_t lds = iter_lds(TW, TH, M, M > 1);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)k_flow_iter<TW, TH, M, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    RC_ALLOW_LDS((k_flow_iter<TW, TH, M, G>), lds);
     a.tw = TW; a.th = TH;
     a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
     hipLaunchKernelGGL((k_flow_iter<TW, TH, M, G>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(RC_BLOCK), lds, s, a);
@@ -1252,10 +1240,6 @@ void rc_launch_flow_iter(const RcIterArgs& a, int pairs, hipStream_t s) {
     pick_runtime_tile(m, b.tw, b.th);
     b.tiles_x = (b.w + b.tw - 1) / b.tw; b.tiles_y = (b.h + b.th - 1) / b.th;
     size_t lds = iter_lds(b.tw, b.th, m, true);
-    static size_t attr = 0;
-    if (lds > attr) {
-        (void)hipFuncSetAttribute((const void*)k_flow_iter<0, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = lds;
-    }
+    RC_ALLOW_LDS((k_flow_iter<0, 0, 0, 0>), lds);
     hipLaunchKernelGGL((k_flow_iter<0, 0, 0, 0>), dim3(b.tiles_x * b.tiles_y, pairs, 1), dim3(RC_BLOCK), lds, s, b);
 }

@@ -317,11 +317,7 @@ extern "C" int rcflow_pyrlk_dev(rc_ctx* ctx, int stream, const uint8_t* d_prev, 
     a.epsilon = epsilon; a.min_eig = min_eig_threshold;
     const int win_n = win_w * win_h;
     size_t lds = 3 * RC_LK_THREADS * sizeof(long long) + (size_t)((win_n + 1) & ~1) * sizeof(short) + (size_t)win_n * sizeof(short2);
-    static size_t attr = 0;
-    if (lds > attr) {
-        (void)hipFuncSetAttribute((const void*)k_lk_track, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = lds;
-    }
+    RC_ALLOW_LDS((k_lk_track), lds);
     hipLaunchKernelGGL(k_lk_track, dim3(npts), dim3(RC_LK_THREADS), lds, s->cur, a);
     RC_HIP(hipGetLastError());
     return RC_OK;

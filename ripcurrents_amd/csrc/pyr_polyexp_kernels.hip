@@ -355,11 +355,7 @@ template <int R>
 static void launch_pyr_rows(const RcPyrArgs& a, int frames, hipStream_t s) {
     const int reg_h = (int)ceil(8 * a.scale_y) + 2 * R + 4;
     const size_t lds = (size_t)reg_h * 32 * sizeof(float2);
-    static size_t attr = 0;
-    if (lds > attr) {
-        (void)hipFuncSetAttribute((const void*)k_pyr_rows<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = lds;
-    }
+    RC_ALLOW_LDS((k_pyr_rows<R>), lds);
     dim3 grid((a.w + 31) / 32, (a.h + 7) / 8, frames);
     hipLaunchKernelGGL(k_pyr_rows<R>, grid, dim3(RC_BLOCK), lds, s, a);
 }
@@ -689,12 +685,7 @@ static void launch_polyexp_th(const RcPolyArgs& a, int frames, hipStream_t s) {
     constexpr int INW = 64 + 2 * RP, INH = TH + 2 * R;
     constexpr size_t lds_hs = sizeof(float) * (3 * (size_t)INH * 64 + 3 * (2 * R + 1)), lds_ub = (size_t)(INH + 2) * (INW + 8);
     constexpr size_t lds = sizeof(float) * (size_t)INH * INW + (lds_hs > lds_ub ? lds_hs : lds_ub);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_polyexp<R, U8, TH, MFMA>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr_set = true;
-    }
+    RC_ALLOW_LDS((k_polyexp<R, U8, TH, MFMA>), lds);
     dim3 grid((a.w + 63) / 64, (a.h + TH - 1) / TH, frames);
     hipLaunchKernelGGL((k_polyexp<R, U8, TH, MFMA>), grid, dim3(RC_POLY_BLOCK), lds, s, a);
 }

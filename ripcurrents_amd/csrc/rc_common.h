@@ -104,6 +104,20 @@ struct RcIterArgs {
     RcWindow win;
 };
 
+// Raises a kernel's dynamic-LDS limit once per (call site, device): the attribute is per device, and a
+// process may hold contexts on several devices.
+#define RC_MAX_DEVICES 64
+#define RC_ALLOW_LDS(fn, lds)                                                                             \
+    do {                                                                                                  \
+        static size_t rc_seen_[RC_MAX_DEVICES] = {0};                                                     \
+        int rc_dev_ = 0;                                                                                  \
+        (void)hipGetDevice(&rc_dev_);                                                                     \
+        if (rc_dev_ >= 0 && rc_dev_ < RC_MAX_DEVICES && (size_t)(lds) > rc_seen_[rc_dev_]) {             \
+            (void)hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)); \
+            rc_seen_[rc_dev_] = (size_t)(lds);                                                            \
+        }                                                                                                 \
+    } while (0)
+
 void rc_launch_pyr(const RcPyrArgs& a, int frames, size_t lds, hipStream_t s);
 void rc_launch_polyexp(const RcPolyArgs& a, int frames, hipStream_t s);
 void rc_launch_flow_iter(const RcIterArgs& a, int pairs, hipStream_t s);
