@@ -275,7 +275,8 @@ int rcflow_pyrlk_u8(rc_ctx* ctx, int stream, const uint8_t* prev, size_t prev_st
 int rcflow_pyrlk_levels(int w, int h, int win_w, int win_h, int max_level);
 
 /* ------------------------------------------------------------------ measurement */
-/* When enabled every kernel launch is bracketed by HIP events on the slot's stream. */
+/* When enabled every kernel launch is bracketed by HIP events on the slot's stream.  Measurement
+ * aid: while it is on, drive the context from one thread only (the event list is per context). */
 int rcflow_profile_enable(rc_ctx* ctx, int on);
 int rcflow_profile_reset(rc_ctx* ctx);
 /* Resolves pending events and returns per-kernel totals.  names[i] points to a static
