@@ -419,3 +419,34 @@ def test_lockstep_stream_batch_matches_per_stream(ctx, use_graph):
             ref = ctx.calcOpticalFlowFarneback(clips[s, t], clips[s, t + 1], None, **RC215)
             assert np.array_equal(got[t][s], ref), (s, t)
     ctx.batch_reset()
+
+
+def test_two_threads_on_two_stream_slots(ctx):
+    """include/rcflow.h: a context is thread-safe across distinct stream indices.  Two host threads,
+    one slot each, different sizes and parameter sets, interleaved calls: same bits as one thread."""
+    import threading
+    jobs = [(0, (320, 240), RC215, 5), (1, (333, 251), MAIN264, 9)]
+    clips = {s: torch.as_tensor(synth.surf_clip(w, h, 6, seed=seed)).cuda() for s, (w, h), _, seed in jobs}
+    ref = {}
+    for s, (w, h), p, _ in jobs:
+        ref[s] = ctx.farneback_clip(clips[s], stream=s, **p).cpu().numpy().copy()
+    ctx.sync(0); ctx.sync(1)
+    got, errs = {}, []
+
+    def work(s, p):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(8):
+                    out = ctx.farneback_clip(clips[s], stream=s, **p)
+                st.synchronize()
+                got[s] = out.cpu().numpy().copy()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(s, p)) for s, _, p, _ in jobs]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errs, errs
+    for s in ref:
+        assert np.array_equal(got[s], ref[s])
