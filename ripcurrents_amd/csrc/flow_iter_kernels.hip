@@ -1163,7 +1163,14 @@ static void launch_w3x2(RcIterArgs a, int pairs, hipStream_t s) {
     else if (a.ablate & 512) launch_rr_t<IN_MODE, G, 4, 3, 2, 64>(a, pairs, s);  // 60x28 tile, 512 threads, 2 blocks per CU
     else if (a.ablate & 1024) launch_rr_t<IN_MODE, G, 2, 3, 4, 32, 16>(a, pairs, s);  // 28x28 tile, 512 threads x 2 rows
     else if (a.ablate & 16384) launch_rr_t<IN_MODE, G, 2, 3, 8, 32, 16>(a, pairs, s); // same, registers capped for 8 waves per SIMD
-    else launch_rr_t<IN_MODE, G, 4, 3, 4>(a, pairs, s);                         // 28x28 tile, 4 blocks per CU
+    else {
+        // A launch of fewer blocks than the GPU holds at once (1024 = 256 CUs x 4) lasts one block's
+        // lifetime: shorter tiles then finish sooner (frame-at-a-time calls, coarse scales).  Same bits.
+        const long long blocks = (long long)((a.w + 27) / 28) * ((a.h + 27) / 28) * pairs;
+        if (blocks < 512) launch_rr_t<IN_MODE, G, 2, 4, 6>(a, pairs, s);          // 28x12 tile
+        else if (blocks < 1024) launch_rr_t<IN_MODE, G, 3, 4, 5>(a, pairs, s);    // 28x20 tile
+        else launch_rr_t<IN_MODE, G, 4, 3, 4>(a, pairs, s);                       // 28x28 tile, 4 blocks per CU
+    }
 }
 
 int rc_flow_iter_can_fuse2(const RcIterArgs& a) { return a.win.m == 1 && a.solve; }

@@ -9,6 +9,9 @@ dev = torch.device("cuda")
 frames = synth.surf_clip(W, H, 8, device=dev)
 ctx = Context(W, H)
 flow = torch.empty((H, W, 2), dtype=torch.float32, device=dev)
+import sys as _s
+for kv in _s.argv[1:]:
+    k, v = kv.split("="); ctx.set_option(k, int(v))
 for i in range(20): ctx.push_frame(frames[i % 8], flow, **P)
 torch.cuda.synchronize()
 ctx.profile_enable(True); ctx.profile_reset()
