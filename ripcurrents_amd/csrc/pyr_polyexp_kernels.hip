@@ -146,10 +146,9 @@ __device__ __forceinline__ float rc_rowpass(const float* b, const float* k) {
 }
 
 template <int R>
-__global__ __launch_bounds__(RC_BLOCK) void k_pyr_direct(RcPyrArgs a) {
+__device__ __forceinline__ void rc_pyr_direct_body(const RcPyrArgs& a, int bx, int by, int z) {
     constexpr int KS = 2 * R + 1, NB = 2 * R + 2, NDW = (2 * R + 8) / 4, NROW = 2 * R + 2;
-    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int z = blockIdx.z;
+    const int dx = bx * 64 + (threadIdx.x & 63), dy = by * 4 + (threadIdx.x >> 6);
     if (dx >= a.w || dy >= a.h) return;
     const int W0 = a.W0, H0 = a.H0;
     float k[KS];
@@ -237,6 +236,11 @@ __global__ __launch_bounds__(RC_BLOCK) void k_pyr_direct(RcPyrArgs a) {
     a.dst[(size_t)slot * a.dst_slot_stride + (size_t)dy * a.w + dx] = r0 * w0 + r1 * w1;
 }
 
+template <int R>
+__global__ __launch_bounds__(RC_BLOCK) void k_pyr_direct(RcPyrArgs a) {
+    rc_pyr_direct_body<R>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
 // ------------------------------------------------------------------------------------
 // Row-pass / column-pass form for any decimation (scales 1..4 at pyr_scale 0.5: 3, 9, 19 and 39
 // taps): a block owns 32 x 8 outputs.  Phase 1: one item = (virtual source row, output column);
@@ -247,11 +251,11 @@ __global__ __launch_bounds__(RC_BLOCK) void k_pyr_direct(RcPyrArgs a) {
 // rows).  Phase 2: one thread per output does the four column filters and the bilinear
 // resize.  Same operation order as k_pyr_level / k_pyr_direct (bit-identical results).
 template <int R>
-__global__ __launch_bounds__(RC_BLOCK) void k_pyr_rows(RcPyrArgs a) {
+__device__ __forceinline__ void rc_pyr_rows_body(const RcPyrArgs& a, int bx, int by, int z, float2* rp) {
     constexpr int KS = 2 * R + 1, NB = 2 * R + 2, NDW = (2 * R + 8) / 4, TWO = 32, THO = 8;
-    extern __shared__ __align__(16) float2 rp[];       // [reg_h][TWO]  row-pass results at (sx, sx + 1)
-    const int tid = threadIdx.x, z = blockIdx.z;
-    const int tx0 = blockIdx.x * TWO, ty0 = blockIdx.y * THO;
+    // rp: [reg_h][TWO]  row-pass results at (sx, sx + 1)
+    const int tid = threadIdx.x;
+    const int tx0 = bx * TWO, ty0 = by * THO;
     const int W0 = a.W0, H0 = a.H0;
     float k[KS];
 #pragma unroll
@@ -352,6 +356,41 @@ __global__ __launch_bounds__(RC_BLOCK) void k_pyr_rows(RcPyrArgs a) {
 }
 
 template <int R>
+__global__ __launch_bounds__(RC_BLOCK) void k_pyr_rows(RcPyrArgs a) {
+    extern __shared__ __align__(16) float2 rc_pyr_smem[];
+    rc_pyr_rows_body<R>(a, blockIdx.x, blockIdx.y, blockIdx.z, rc_pyr_smem);
+}
+
+// Scales 1 and 2 of a pyr_scale = 0.5 pyramid (3 and 9 taps) in ONE launch: the two grids are
+// independent and, for a frame or two, each is smaller than the GPU; blocks below n1 take the
+// scale-1 tile code, the rest the scale-2 tile code.  Same bits as the separate launches.
+__global__ __launch_bounds__(RC_BLOCK) void k_pyr_pair_3_9(RcPyrArgs a1, RcPyrArgs a2, int gx1, int gy1, int n1,
+                                                           int gx2, int gy2) {
+    extern __shared__ __align__(16) float2 rc_pyr_smem[];
+    int id = blockIdx.x;
+    if (id < n1) {
+        const int z = id / (gx1 * gy1), r = id - z * gx1 * gy1;
+        rc_pyr_direct_body<1>(a1, r % gx1, r / gx1, z);
+    } else {
+        id -= n1;
+        const int z = id / (gx2 * gy2), r = id - z * gx2 * gy2;
+        rc_pyr_rows_body<4>(a2, r % gx2, r / gx2, z, rc_pyr_smem);
+    }
+}
+
+// true when the pair launch applies: 3 + 9 taps, row-pass LDS within the default limit
+int rc_pyr_pair_ok(const RcPyrArgs& a1, const RcPyrArgs& a2) {
+    const size_t lds = ((size_t)ceil(8 * a2.scale_y) + a2.ksize + 3) * 32 * sizeof(float2);
+    return a1.ksize == 3 && a2.ksize == 9 && !a1.direct && !a2.direct && lds <= 48 * 1024;
+}
+void rc_launch_pyr_pair(const RcPyrArgs& a1, const RcPyrArgs& a2, int frames, hipStream_t s) {
+    const int gx1 = (a1.w + 63) / 64, gy1 = (a1.h + 3) / 4, gx2 = (a2.w + 31) / 32, gy2 = (a2.h + 7) / 8;
+    const int n1 = gx1 * gy1 * frames, n2 = gx2 * gy2 * frames;
+    const size_t lds = ((size_t)ceil(8 * a2.scale_y) + 2 * 4 + 4) * 32 * sizeof(float2);
+    hipLaunchKernelGGL(k_pyr_pair_3_9, dim3(n1 + n2), dim3(RC_BLOCK), lds, s, a1, a2, gx1, gy1, n1, gx2, gy2);
+}
+
+template <int R>
 static void launch_pyr_rows(const RcPyrArgs& a, int frames, hipStream_t s) {
     const int reg_h = (int)ceil(8 * a.scale_y) + 2 * R + 4;
     const size_t lds = (size_t)reg_h * 32 * sizeof(float2);
@@ -396,17 +435,15 @@ void rc_launch_pyr(const RcPyrArgs& a, int frames, size_t lds, hipStream_t s) {
 typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
 
 template <int R, int U8, int TH, int MFMA>
-__global__ __launch_bounds__(RC_POLY_BLOCK) void k_polyexp(RcPolyArgs a) {
+__device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int by, int z, float* smf) {
     constexpr int TW = 64, RP = (R + 3) & ~3;
     constexpr int INW = TW + 2 * RP, INH = TH + 2 * R;
     constexpr int NV = 4 + 2 * RP;
     constexpr int NDW = (INW + 8) / 4, UBW = 4 * NDW, UBH = INH + 2;   // u8 staging: pitch UBW bytes
-    extern __shared__ __align__(16) float smf[];
     float* tin = smf;                // [INH][INW]
     float* hs = smf + INH * INW;     // [3][INH][TW]
     const int tid = threadIdx.x;
-    const int z = blockIdx.z;
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const int tx0 = bx * TW, ty0 = by * TH;
     const int w = a.w, h = a.h;
     const int slot = (a.slot0 + z * a.zstep) % a.nslots;
     float dc;
@@ -677,6 +714,63 @@ __global__ __launch_bounds__(RC_POLY_BLOCK) void k_polyexp(RcPolyArgs a) {
             }
         }
     }
+}
+
+template <int R, int U8, int TH, int MFMA>
+__global__ __launch_bounds__(RC_POLY_BLOCK) void k_polyexp(RcPolyArgs a) {
+    extern __shared__ __align__(16) float rc_poly_smem[];
+    rc_polyexp_body<R, U8, TH, MFMA>(a, blockIdx.x, blockIdx.y, blockIdx.z, rc_poly_smem);
+}
+
+// The expansions of up to three scales of one frame (or a few) in ONE launch: scale 0 from the 8-bit
+// frames (pyramid fused), scales 1 and 2 from their pyramid images.  The grids are independent and each
+// is no bigger than the GPU for a frame or two, so the launch lasts about as long as its largest part
+// instead of the sum of three.  Same tile code, same bits.
+template <int R>
+__global__ __launch_bounds__(RC_POLY_BLOCK) void k_polyexp_multi(RcPolyArgs a0, RcPolyArgs a1, RcPolyArgs a2, int n0, int n1,
+                                                                 int gx0, int gy0, int gx1, int gy1, int gx2, int gy2) {
+    extern __shared__ __align__(16) float rc_poly_smem[];
+    int id = blockIdx.x;
+    if (id < n0) {
+        const int z = id / (gx0 * gy0), r = id - z * gx0 * gy0;
+        rc_polyexp_body<R, 1, 32, 0>(a0, r % gx0, r / gx0, z, rc_poly_smem);
+    } else if (id < n0 + n1) {
+        id -= n0;
+        const int z = id / (gx1 * gy1), r = id - z * gx1 * gy1;
+        rc_polyexp_body<R, 0, 32, 0>(a1, r % gx1, r / gx1, z, rc_poly_smem);
+    } else {
+        id -= n0 + n1;
+        const int z = id / (gx2 * gy2), r = id - z * gx2 * gy2;
+        rc_polyexp_body<R, 0, 32, 0>(a2, r % gx2, r / gx2, z, rc_poly_smem);
+    }
+}
+
+template <int R>
+static void launch_polyexp_multi_t(const RcPolyArgs* a, int nlev, int frames, hipStream_t s) {
+    constexpr int RP = (R + 3) & ~3;
+    constexpr int INW = 64 + 2 * RP, INH = 32 + 2 * R;
+    constexpr size_t lds_hs = sizeof(float) * (3 * (size_t)INH * 64 + 3 * (2 * R + 1)), lds_ub = (size_t)(INH + 2) * (INW + 8);
+    constexpr size_t lds = sizeof(float) * (size_t)INH * INW + (lds_hs > lds_ub ? lds_hs : lds_ub);
+    RC_ALLOW_LDS((k_polyexp_multi<R>), lds);
+    int gx[3] = {1, 1, 1}, gy[3] = {1, 1, 1}, n[3] = {0, 0, 0};
+    for (int k = 0; k < nlev; k++) { gx[k] = (a[k].w + 63) / 64; gy[k] = (a[k].h + 31) / 32; n[k] = gx[k] * gy[k] * frames; }
+    const RcPolyArgs& a2 = nlev > 2 ? a[2] : a[1];
+    hipLaunchKernelGGL((k_polyexp_multi<R>), dim3(n[0] + n[1] + n[2]), dim3(RC_POLY_BLOCK), lds, s, a[0], a[1], a2, n[0], n[1],
+                       gx[0], gy[0], gx[1], gy[1], gx[2], gy[2]);
+}
+
+// a[0] must be the 8-bit scale 0, a[1..nlev-1] float scales; nlev = 2 or 3; the default 32-row VALU tiles
+int rc_polyexp_multi_ok(const RcPolyArgs* a, int nlev) {
+    if (nlev < 2 || nlev > 3 || !a[0].src8 || a[0].tile_h != 32 || !a[0].valu_vertical) return 0;
+    for (int k = 1; k < nlev; k++) if (a[k].src8 || a[k].pk.n_eff != a[0].pk.n_eff) return 0;
+    const int n = a[0].pk.n_eff;
+    return n == 3 || n == 5 || n == 7;
+}
+void rc_launch_polyexp_multi(const RcPolyArgs* a, int nlev, int frames, hipStream_t s) {
+    const int n = a[0].pk.n_eff;
+    if (n <= 3) launch_polyexp_multi_t<3>(a, nlev, frames, s);
+    else if (n <= 5) launch_polyexp_multi_t<5>(a, nlev, frames, s);
+    else launch_polyexp_multi_t<7>(a, nlev, frames, s);
 }
 
 template <int R, int U8, int TH, int MFMA>

@@ -120,6 +120,11 @@ struct RcIterArgs {
 
 void rc_launch_pyr(const RcPyrArgs& a, int frames, size_t lds, hipStream_t s);
 void rc_launch_polyexp(const RcPolyArgs& a, int frames, hipStream_t s);
+// merged launches for a frame or two (see pyr_polyexp_kernels.hip)
+int rc_pyr_pair_ok(const RcPyrArgs& a1, const RcPyrArgs& a2);
+void rc_launch_pyr_pair(const RcPyrArgs& a1, const RcPyrArgs& a2, int frames, hipStream_t s);
+int rc_polyexp_multi_ok(const RcPolyArgs* a, int nlev);
+void rc_launch_polyexp_multi(const RcPolyArgs* a, int nlev, int frames, hipStream_t s);
 void rc_launch_flow_iter(const RcIterArgs& a, int pairs, hipStream_t s);
 // two iterations in one launch (only where rc_flow_iter_can_fuse2 says so)
 int rc_flow_iter_can_fuse2(const RcIterArgs& a);

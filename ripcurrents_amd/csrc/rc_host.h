@@ -77,6 +77,7 @@ struct rc_ctx {
     int fuse_iters = 1;
     int xcd_remap = 1;
     int poly_tile_h = 32;
+    int merge_small = 1;       // option "merge_small": merged pyramid / expansion launches for calls of one or two frames
     int overlap = 0;           // option "overlap": clip path on two streams (measured: no gain, the grids fill the GPU)
     int poly_mfma = 0;          // option "poly_mfma": vertical pass of the expansion on the matrix cores (measured 25 % slower)
     int hist_blocks = 0;       // option "hist_blocks": cap on histogram blocks per launch (0 = default)

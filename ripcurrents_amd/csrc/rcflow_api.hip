@@ -246,6 +246,8 @@ extern "C" int rcflow_set_option(rc_ctx* ctx, const char* name, int value) {
         ctx->hist_blocks = value;
     } else if (!strcmp(name, "overlap")) {
         ctx->overlap = value ? 1 : 0;
+    } else if (!strcmp(name, "merge_small")) {
+        ctx->merge_small = value ? 1 : 0;
     } else if (!strcmp(name, "poly_mfma")) {
         ctx->poly_mfma = value ? 1 : 0;
     } else if (!strcmp(name, "poly_tile_h")) {
@@ -519,40 +521,62 @@ static int ensure_plan(rc_ctx* ctx, RcSlot& s, int w, int h, const rc_farneback_
 static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t frame_stride, size_t step,
                          int count, int dslot0, int zstep = 1) {
     RcPlan& pl = s.plan;
+    RcPolyArgs qa[RC_MAX_LEVELS];
+    RcPyrArgs pa[RC_MAX_LEVELS];
     for (int k = 0; k < pl.nlev; k++) {
         const RcLevel& L = pl.lv[k];
         size_t n = (size_t)L.w * L.h;
-        RcPolyArgs qa;
-        memset(&qa, 0, sizeof(qa));
-        qa.RA = (float4*)s.RA[k].p; qa.RB = (float*)s.RB[k].p; qa.R_slot_stride = n;
-        qa.slot0 = dslot0; qa.nslots = pl.nslots; qa.zstep = zstep; qa.w = L.w; qa.h = L.h; qa.pk = pl.pk;
-        qa.tile_h = ctx->poly_tile_h; qa.no_fast_u8 = (ctx->ablate >> 11) & 1; qa.valu_vertical = !ctx->poly_mfma;
+        RcPolyArgs& q = qa[k];
+        memset(&q, 0, sizeof(q));
+        q.RA = (float4*)s.RA[k].p; q.RB = (float*)s.RB[k].p; q.R_slot_stride = n;
+        q.slot0 = dslot0; q.nslots = pl.nslots; q.zstep = zstep; q.w = L.w; q.h = L.h; q.pk = pl.pk;
+        q.tile_h = ctx->poly_tile_h; q.no_fast_u8 = (ctx->ablate >> 11) & 1; q.valu_vertical = !ctx->poly_mfma;
         if (k == 0) {
             // scale 0: pyramid (3x3 blur, identity resize) fused into the expansion
-            qa.src8 = d_src; qa.src8_step = step; qa.src8_frame_stride = frame_stride;
-            // pyramid (N0 + 4 N0) + expansion (4 N0 + 20 N0) for the two stages fused here
-            RcProfScope ps(ctx, s.cur, RC_K_POLY, k, (double)count * 21. * n, (double)count * 29. * n);
-            rc_launch_polyexp(qa, count, s.cur);
+            q.src8 = d_src; q.src8_step = step; q.src8_frame_stride = frame_stride;
             continue;
         }
-        RcPyrArgs pa;
-        pa.src = d_src; pa.src_step = step; pa.src_frame_stride = frame_stride;
-        pa.W0 = pl.w; pa.H0 = pl.h;
-        pa.dst = (float*)s.I[k].p; pa.dst_slot_stride = n;
-        pa.dslot0 = dslot0; pa.nslots = pl.nslots; pa.zstep = zstep;
-        pa.w = L.w; pa.h = L.h; pa.scale_x = L.scale_x; pa.scale_y = L.scale_y;
-        pa.ksize = L.ksize; pa.kern = (const float*)s.kern.p + pl.kern_off[k];
-        pa.tw = L.pyr_tw; pa.th = L.pyr_th; pa.reg_wp = L.pyr_reg_w; pa.reg_hmax = L.pyr_reg_h;
-        pa.direct = (ctx->ablate >> 12) & 1;
-        {
-            RcProfScope ps(ctx, s.cur, RC_K_PYR, k, (double)count * ((double)pl.w * pl.h + 4. * n));
-            rc_launch_pyr(pa, count, L.pyr_lds, s.cur);
-        }
-        qa.I = (const float*)s.I[k].p; qa.I_slot_stride = n;
-        {
-            RcProfScope ps(ctx, s.cur, RC_K_POLY, k, (double)count * 24. * n);
-            rc_launch_polyexp(qa, count, s.cur);
-        }
+        q.I = (const float*)s.I[k].p; q.I_slot_stride = n;
+        RcPyrArgs& p = pa[k];
+        memset(&p, 0, sizeof(p));
+        p.src = d_src; p.src_step = step; p.src_frame_stride = frame_stride;
+        p.W0 = pl.w; p.H0 = pl.h;
+        p.dst = (float*)s.I[k].p; p.dst_slot_stride = n;
+        p.dslot0 = dslot0; p.nslots = pl.nslots; p.zstep = zstep;
+        p.w = L.w; p.h = L.h; p.scale_x = L.scale_x; p.scale_y = L.scale_y;
+        p.ksize = L.ksize; p.kern = (const float*)s.kern.p + pl.kern_off[k];
+        p.tw = L.pyr_tw; p.th = L.pyr_th; p.reg_wp = L.pyr_reg_w; p.reg_hmax = L.pyr_reg_h;
+        p.direct = (ctx->ablate >> 12) & 1;
+    }
+    auto npx = [&](int k) { return (double)pl.lv[k].w * pl.lv[k].h; };
+    // A frame or two per call (the frame-at-a-time loop, two-image calls): the scales' grids are each
+    // smaller than the GPU and independent of one another, so scales 1 + 2 of the pyramid share one launch
+    // and the expansions of scales 0..2 another (block-index dispatch; same tile code, same bits).
+    const bool merge = ctx->merge_small && count <= 2;
+    int k_pyr = 1;
+    if (merge && pl.nlev >= 3 && rc_pyr_pair_ok(pa[1], pa[2])) {
+        RcProfScope ps(ctx, s.cur, RC_K_PYR, 1, (double)count * (2. * npx(0) + 4. * (npx(1) + npx(2))));
+        rc_launch_pyr_pair(pa[1], pa[2], count, s.cur);
+        k_pyr = 3;
+    }
+    for (int k = k_pyr; k < pl.nlev; k++) {
+        RcProfScope ps(ctx, s.cur, RC_K_PYR, k, (double)count * (npx(0) + 4. * npx(k)));
+        rc_launch_pyr(pa[k], count, pl.lv[k].pyr_lds, s.cur);
+    }
+    int k_poly = 0;
+    const int nm = pl.nlev < 3 ? pl.nlev : 3;
+    if (merge && nm >= 2 && rc_polyexp_multi_ok(qa, nm)) {
+        double alg = 21. * npx(0), model = 29. * npx(0);
+        for (int k = 1; k < nm; k++) { alg += 24. * npx(k); model += 24. * npx(k); }
+        RcProfScope ps(ctx, s.cur, RC_K_POLY, 0, (double)count * alg, (double)count * model);
+        rc_launch_polyexp_multi(qa, nm, count, s.cur);
+        k_poly = nm;
+    }
+    for (int k = k_poly; k < pl.nlev; k++) {
+        // SURVEY 8(d), scale 0: pyramid (N0 + 4 N0) + expansion (4 N0 + 20 N0) for the two stages fused there
+        RcProfScope ps(ctx, s.cur, RC_K_POLY, k, (double)count * (k == 0 ? 21. : 24.) * npx(k),
+                       k == 0 ? (double)count * 29. * npx(0) : -1.);
+        rc_launch_polyexp(qa[k], count, s.cur);
     }
     RC_HIP(hipGetLastError());
     return RC_OK;
