@@ -238,6 +238,10 @@ int rcflow_create_edges_dev(rc_ctx* ctx, int stream, const uint8_t* d_outmask, s
  * (ripcurrents.cpp:209-210, main.cpp:258-259): 8UC3 BGR frame in, 8UC1 out. */
 int rcflow_resize_bgr_to_gray_dev(rc_ctx* ctx, int stream, const uint8_t* d_bgr, size_t step,
                                   int sw, int sh, uint8_t* d_gray, size_t gray_step, int dw, int dh);
+/* The same with INTER_AREA, as the reference resizes the FIRST frame of a run (ripcurrents.cpp:186,
+ * main.cpp:126, 223, ...); shrinking only. */
+int rcflow_resize_area_bgr_to_gray_dev(rc_ctx* ctx, int stream, const uint8_t* d_bgr, size_t step,
+                                       int sw, int sh, uint8_t* d_gray, size_t gray_step, int dw, int dh);
 
 /* Display path, ripcurrents.cpp:233-273 (= streamline_displacement / _total_motion / _ratio /
  * _positions, ripcurrents_module.cpp:13-60) on the slot's streamline field (rcflow_advect_field_dev):

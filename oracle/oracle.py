@@ -389,3 +389,13 @@ def hsv_to_bgr(hsv):
     out = np.zeros((h, w, 3), np.float32)
     lib().orc_hsv_to_bgr_f32(_p(hsv), C.c_size_t(hsv.strides[0]), w, h, _p(out), C.c_size_t(out.strides[0]))
     return out
+
+
+def resize_area_bgr_to_gray(bgr, dw, dh):
+    """resize(frame, Size(dw, dh), INTER_AREA) + cvtColor(BGR2GRAY) (the first frame, ripcurrents.cpp:186)."""
+    bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+    sh, sw = bgr.shape[:2]
+    out = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_area_bgr_to_gray(_p(bgr, C.c_uint8), C.c_size_t(bgr.strides[0]), sw, sh, _p(out, C.c_uint8),
+                                      C.c_size_t(out.strides[0]), dw, dh)
+    return out

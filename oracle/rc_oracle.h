@@ -141,6 +141,11 @@ void orc_ellipse5(uint8_t kernel[25]);   /* getStructuringElement(MORPH_ELLIPSE,
 void orc_resize_bgr_to_gray(const uint8_t* bgr, size_t step, int sw, int sh, uint8_t* gray,
                             size_t gray_step, int dw, int dh);
 
+/* The first frame's pre-processing (ripcurrents.cpp:186, main.cpp:126, ...): resize INTER_AREA on 8UC3
+ * (imgproc resize.cpp resizeAreaFast_ for integer factors, resizeArea_ otherwise) + cvtColor(BGR2GRAY). */
+void orc_resize_area_bgr_to_gray(const uint8_t* bgr, size_t step, int sw, int sh, uint8_t* gray,
+                                 size_t gray_step, int dw, int dh);
+
 /* Display path (section 8(f) row 4; display_oracle.cpp): ripcurrents.cpp:233-273 and :405 */
 void orc_jet_lut(uint8_t* lut_bgr /* 256*3: applyColorMap(COLORMAP_JET) */);
 /* which 0 = streamline_displacement, 1 = streamline_total_motion, 2 = streamline_ratio

@@ -540,4 +540,85 @@ void orc_resize_bgr_to_gray(const uint8_t* bgr, size_t step, int sw, int sh, uin
     }
 }
 
+// resize 8UC3 INTER_AREA (the first frame: ripcurrents.cpp:186, main.cpp:126 ...) + cvtColor BGR2GRAY.
+// imgproc resize.cpp: integer scale factors take resizeAreaFast_ (sum of the area; 2 x 2 through the SIMD
+// path (sum + 2) >> 2, otherwise saturate_cast(sum * (1.f / area))); anything else takes resizeArea_ with
+// the DecimateAlpha tables of computeResizeAreaTab (float accumulation, row buffer then column sum).
+static int area_tab(int ssize, int dsize, double scale, std::vector<int>& si, std::vector<int>& di,
+                    std::vector<float>& alpha) {
+    si.clear(); di.clear(); alpha.clear();
+    for (int dx = 0; dx < dsize; dx++) {
+        double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        double cellWidth = std::min(scale, ssize - fsx1);
+        int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+        sx2 = std::min(sx2, ssize - 1);
+        sx1 = std::min(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3) { di.push_back(dx); si.push_back(sx1 - 1); alpha.push_back((float)((sx1 - fsx1) / cellWidth)); }
+        for (int sx = sx1; sx < sx2; sx++) { di.push_back(dx); si.push_back(sx); alpha.push_back((float)(1.0 / cellWidth)); }
+        if (fsx2 - sx2 > 1e-3) {
+            di.push_back(dx); si.push_back(sx2);
+            alpha.push_back((float)(std::min(std::min(fsx2 - sx2, 1.), cellWidth) / cellWidth));
+        }
+    }
+    return (int)di.size();
+}
+
+void orc_resize_area_bgr_to_gray(const uint8_t* bgr, size_t step, int sw, int sh, uint8_t* gray, size_t gray_step,
+                                 int dw, int dh) {
+    const int cn = 3;
+    double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    std::vector<uint8_t> res((size_t)dw * dh * cn);
+    int iscale_x = (int)std::nearbyint(scale_x), iscale_y = (int)std::nearbyint(scale_y);   // saturate_cast<int>
+    bool is_area_fast = std::abs(scale_x - iscale_x) < DBL_EPSILON && std::abs(scale_y - iscale_y) < DBL_EPSILON;
+    if (scale_x >= 1 && scale_y >= 1 && is_area_fast) {
+        const int area = iscale_x * iscale_y;
+        const float scale = 1.f / area;
+        for (int dy = 0; dy < dh; dy++)
+            for (int dx = 0; dx < dw; dx++)
+                for (int c = 0; c < cn; c++) {
+                    int sum = 0;
+                    for (int ky = 0; ky < iscale_y; ky++)
+                        for (int kx = 0; kx < iscale_x; kx++)
+                            sum += bgr[(size_t)(dy * iscale_y + ky) * step + (size_t)(dx * iscale_x + kx) * cn + c];
+                    int v = (iscale_x == 2 && iscale_y == 2) ? (sum + 2) >> 2 : (int)std::nearbyintf(sum * scale);
+                    res[((size_t)dy * dw + dx) * cn + c] = (uint8_t)std::min(std::max(v, 0), 255);
+                }
+    } else {
+        // (scale < 1 in either direction is INTER_LINEAR-like upstream; the reference only shrinks)
+        std::vector<int> xsi, xdi, ysi, ydi;
+        std::vector<float> xa, ya;
+        int xn = area_tab(sw, dw, scale_x, xsi, xdi, xa), yn = area_tab(sh, dh, scale_y, ysi, ydi, ya);
+        std::vector<float> buf((size_t)dw * cn), sum((size_t)dw * cn, 0.f);
+        int prev_dy = ydi[0];
+        auto flush = [&](int dy) {
+            for (int i = 0; i < dw * cn; i++) {
+                float v = sum[i];
+                int q = std::fabs(v) < 2147483648.f ? (int)std::nearbyintf(v) : INT32_MIN;
+                res[(size_t)dy * dw * cn + i] = (uint8_t)std::min(std::max(q, 0), 255);
+            }
+        };
+        for (int j = 0; j < yn; j++) {
+            const float beta = ya[j];
+            const int dy = ydi[j];
+            const uint8_t* S = bgr + (size_t)ysi[j] * step;
+            std::fill(buf.begin(), buf.end(), 0.f);
+            for (int k = 0; k < xn; k++)
+                for (int c = 0; c < cn; c++) buf[xdi[k] * cn + c] += S[xsi[k] * cn + c] * xa[k];
+            if (dy != prev_dy) {
+                flush(prev_dy);
+                for (int i = 0; i < dw * cn; i++) sum[i] = beta * buf[i];
+                prev_dy = dy;
+            } else {
+                for (int i = 0; i < dw * cn; i++) sum[i] += beta * buf[i];
+            }
+        }
+        flush(prev_dy);
+    }
+    for (int dy = 0; dy < dh; dy++)
+        for (int dx = 0; dx < dw; dx++) {
+            const uint8_t* px = res.data() + ((size_t)dy * dw + dx) * cn;
+            gray[(size_t)dy * gray_step + dx] = (uint8_t)((px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + (1 << 13)) >> 14);
+        }
+}
+
 }  // extern "C"

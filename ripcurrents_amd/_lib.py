@@ -78,6 +78,7 @@ SIGNATURES = {
     "rcflow_shear_rate_to_color_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz, C.POINTER(_f)],
     "rcflow_create_edges_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz],
     "rcflow_resize_bgr_to_gray_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz, _i, _i],
+    "rcflow_resize_area_bgr_to_gray_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz, _i, _i],
     "rcflow_streamline_display_dev": [_vp, _i, _i, _vp, _sz, C.POINTER(_f)],
     "rcflow_streamline_positions_dev": [_vp, _i, _vp, _sz],
     "rcflow_hsv_to_bgr_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz],

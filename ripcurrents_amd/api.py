@@ -440,14 +440,15 @@ class Context:
                                                 out.stride(0)))
         return out
 
-    def resize_bgr_to_gray(self, frame, dw, dh, stream=0):
-        """resize(frame, Size(dw,dh), INTER_LINEAR) + cvtColor(BGR2GRAY) (ripcurrents.cpp:209-210)."""
+    def resize_bgr_to_gray(self, frame, dw, dh, stream=0, interpolation="linear"):
+        """resize(frame, Size(dw,dh), INTER_LINEAR) + cvtColor(BGR2GRAY) (ripcurrents.cpp:209-210);
+        interpolation="area": INTER_AREA, as the reference resizes the first frame (ripcurrents.cpp:186)."""
         f = self._dev(frame, torch.uint8).contiguous()
         sh, sw = f.shape[:2]
         out = torch.empty((dh, dw), dtype=torch.uint8, device=self.device)
         self._bind(stream)
-        check(self._lib.rcflow_resize_bgr_to_gray_dev(self._h, stream, self._ptr(f), f.stride(0), sw, sh,
-                                                      self._ptr(out), out.stride(0), dw, dh))
+        fn = self._lib.rcflow_resize_area_bgr_to_gray_dev if interpolation == "area" else self._lib.rcflow_resize_bgr_to_gray_dev
+        check(fn(self._h, stream, self._ptr(f), f.stride(0), sw, sh, self._ptr(out), out.stride(0), dw, dh))
         return out
 
     def _an_size(self, stream):

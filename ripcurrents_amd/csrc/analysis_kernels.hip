@@ -1266,3 +1266,122 @@ extern "C" int rcflow_measure_memory_roof(rc_ctx* ctx, int stream, size_t bytes,
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
+
+// ===================================================================== INTER_AREA pre-processing
+// resize(frame, Size(dw, dh), 0, 0, INTER_AREA) + cvtColor(BGR2GRAY) for the first frame of a run
+// (ripcurrents.cpp:186, main.cpp:126, ...).  resize.cpp: integer factors -> resizeAreaFast_ (sum of the
+// area; 2 x 2: (sum + 2) >> 2 as its SIMD path does, else saturate_cast(sum * (1.f / area))); otherwise
+// resizeArea_ with the DecimateAlpha tables of computeResizeAreaTab: per source row a float row
+// buffer buf += S * alpha (table order), then sum = beta * buf for the first row of an output row and
+// sum += beta * buf after it.  One thread per output pixel reproduces exactly that order.
+struct RcAreaArgs {
+    const uint8_t* bgr; size_t step;
+    int sw, sh, dw, dh;
+    int fast, iscale_x, iscale_y;
+    const int* xstart; const int* xsi; const float* xalpha;    // xstart has dw + 1 entries
+    const int* ystart; const int* ysi; const float* yalpha;
+    uint8_t* gray; size_t gray_step;
+};
+
+__global__ __launch_bounds__(RC_BLOCK) void k_resize_area_bgr_to_gray(RcAreaArgs a) {
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= a.dw || dy >= a.dh) return;
+    int px[3];
+    if (a.fast) {
+        int sum[3] = {0, 0, 0};
+        for (int ky = 0; ky < a.iscale_y; ky++) {
+            const uint8_t* S = a.bgr + (size_t)(dy * a.iscale_y + ky) * a.step + (size_t)dx * a.iscale_x * 3;
+            for (int kx = 0; kx < a.iscale_x; kx++) { sum[0] += S[3 * kx]; sum[1] += S[3 * kx + 1]; sum[2] += S[3 * kx + 2]; }
+        }
+        const float scale = 1.f / (float)(a.iscale_x * a.iscale_y);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            int v = (a.iscale_x == 2 && a.iscale_y == 2) ? (sum[c] + 2) >> 2 : (int)rintf((float)sum[c] * scale);
+            px[c] = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+    } else {
+        float sum[3] = {0.f, 0.f, 0.f};
+        const int x0 = a.xstart[dx], x1 = a.xstart[dx + 1], y0 = a.ystart[dy], y1 = a.ystart[dy + 1];
+        for (int j = y0; j < y1; j++) {
+            const uint8_t* S = a.bgr + (size_t)a.ysi[j] * a.step;
+            const float beta = a.yalpha[j];
+            float buf[3] = {0.f, 0.f, 0.f};
+            for (int k = x0; k < x1; k++) {
+                const uint8_t* p = S + 3 * a.xsi[k];
+                const float al = a.xalpha[k];
+                buf[0] += (float)p[0] * al; buf[1] += (float)p[1] * al; buf[2] += (float)p[2] * al;
+            }
+            if (j == y0) { sum[0] = beta * buf[0]; sum[1] = beta * buf[1]; sum[2] = beta * buf[2]; }
+            else { sum[0] += beta * buf[0]; sum[1] += beta * buf[1]; sum[2] += beta * buf[2]; }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            int v = fabsf(sum[c]) < 2147483648.f ? (int)rintf(sum[c]) : (int)0x80000000;
+            px[c] = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+    }
+    a.gray[(size_t)dy * a.gray_step + dx] = (uint8_t)((px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + (1 << 13)) >> 14);
+}
+
+// computeResizeAreaTab (resize.cpp), grouped by destination index
+static void area_tab(int ssize, int dsize, double scale, std::vector<int>& start, std::vector<int>& si,
+                     std::vector<float>& alpha) {
+    start.assign(dsize + 1, 0); si.clear(); alpha.clear();
+    for (int dx = 0; dx < dsize; dx++) {
+        start[dx] = (int)si.size();
+        double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        double cell = std::min(scale, ssize - fsx1);
+        int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+        sx2 = std::min(sx2, ssize - 1);
+        sx1 = std::min(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3) { si.push_back(sx1 - 1); alpha.push_back((float)((sx1 - fsx1) / cell)); }
+        for (int sx = sx1; sx < sx2; sx++) { si.push_back(sx); alpha.push_back((float)(1.0 / cell)); }
+        if (fsx2 - sx2 > 1e-3) { si.push_back(sx2); alpha.push_back((float)(std::min(std::min(fsx2 - sx2, 1.), cell) / cell)); }
+    }
+    start[dsize] = (int)si.size();
+}
+
+extern "C" int rcflow_resize_area_bgr_to_gray_dev(rc_ctx* ctx, int stream, const uint8_t* d_bgr, size_t step, int sw,
+                                                  int sh, uint8_t* d_gray, size_t gray_step, int dw, int dh) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    if (!d_bgr || !d_gray || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || step < (size_t)sw * 3 || gray_step < (size_t)dw) {
+        rc_set_error("bad frame arguments");
+        return RC_EINVAL;
+    }
+    if (dw > sw || dh > sh) { rc_set_error("INTER_AREA is implemented for shrinking only (the reference's use)"); return RC_EINVAL; }
+    RC_HIP(hipSetDevice(ctx->device));
+    const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    const int isx = (int)nearbyint(scale_x), isy = (int)nearbyint(scale_y);
+    RcAreaArgs a;
+    memset(&a, 0, sizeof(a));
+    a.bgr = d_bgr; a.step = step; a.sw = sw; a.sh = sh; a.dw = dw; a.dh = dh;
+    a.gray = d_gray; a.gray_step = gray_step;
+    a.fast = (fabs(scale_x - isx) < DBL_EPSILON && fabs(scale_y - isy) < DBL_EPSILON) ? 1 : 0;
+    a.iscale_x = isx; a.iscale_y = isy;
+    if (!a.fast) {
+        std::vector<int> xs, xi, ys, yi;
+        std::vector<float> xa, ya;
+        area_tab(sw, dw, scale_x, xs, xi, xa);
+        area_tab(sh, dh, scale_y, ys, yi, ya);
+        const size_t nx = xi.size(), ny = yi.size();
+        const size_t bytes = 4 * ((size_t)(dw + 1) + 2 * nx + (size_t)(dh + 1) + 2 * ny);
+        int rc = rc_buf_ensure(s->area_tab, bytes);
+        if (rc) return rc;
+        int* base = (int*)s->area_tab.p;
+        int* d_xs = base; int* d_xi = d_xs + (dw + 1); float* d_xa = (float*)(d_xi + nx);
+        int* d_ys = (int*)(d_xa + nx); int* d_yi = d_ys + (dh + 1); float* d_ya = (float*)(d_yi + ny);
+        // the tables are tiny; the blocking copies also order them before the launch on any stream
+        RC_HIP(hipStreamSynchronize(s->cur));      // a previous launch may still read the old tables
+        RC_HIP(hipMemcpy(d_xs, xs.data(), 4 * (dw + 1), hipMemcpyHostToDevice));
+        RC_HIP(hipMemcpy(d_xi, xi.data(), 4 * nx, hipMemcpyHostToDevice));
+        RC_HIP(hipMemcpy(d_xa, xa.data(), 4 * nx, hipMemcpyHostToDevice));
+        RC_HIP(hipMemcpy(d_ys, ys.data(), 4 * (dh + 1), hipMemcpyHostToDevice));
+        RC_HIP(hipMemcpy(d_yi, yi.data(), 4 * ny, hipMemcpyHostToDevice));
+        RC_HIP(hipMemcpy(d_ya, ya.data(), 4 * ny, hipMemcpyHostToDevice));
+        a.xstart = d_xs; a.xsi = d_xi; a.xalpha = d_xa; a.ystart = d_ys; a.ysi = d_yi; a.yalpha = d_ya;
+    }
+    hipLaunchKernelGGL(k_resize_area_bgr_to_gray, dim3((dw + 63) / 64, (dh + 3) / 4), dim3(RC_BLOCK), 0, s->cur, a);
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}

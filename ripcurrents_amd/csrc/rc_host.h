@@ -52,6 +52,7 @@ struct RcSlot {
     RcBuf FA[RC_MAX_LEVELS], FB[RC_MAX_LEVELS];
     RcBuf stage_u8, stage_flow, stage_f32[4];
     RcBuf lk;                  // sparse PyrLK pyramids + derivatives (lk_kernels.hip)
+    RcBuf area_tab;            // INTER_AREA decimation tables
     int primed = 0, cur_slot = 0;
     // lockstep batch of streams (rcflow_push_batch_dev): parity of the ring, captured graphs
     int batch_primed = 0, batch_cur = 0;

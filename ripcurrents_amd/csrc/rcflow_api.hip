@@ -179,7 +179,7 @@ static void slot_free(RcSlot& s) {
         rc_buf_free(s.FA[k]); rc_buf_free(s.FB[k]);
     }
     rc_batch_graph_drop(s);
-    rc_buf_free(s.stage_u8); rc_buf_free(s.stage_flow); rc_buf_free(s.lk);
+    rc_buf_free(s.stage_u8); rc_buf_free(s.stage_flow); rc_buf_free(s.lk); rc_buf_free(s.area_tab);
     for (auto& b : s.stage_f32) rc_buf_free(b);
     rc_buf_free(s.an.hist); rc_buf_free(s.an.hist_part); rc_buf_free(s.an.thr); rc_buf_free(s.an.acc);
     rc_buf_free(s.an.pt); rc_buf_free(s.an.dist); rc_buf_free(s.an.scratch); rc_buf_free(s.an.jet);

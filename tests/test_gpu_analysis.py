@@ -309,6 +309,19 @@ def test_resize_bgr_to_gray_exact(ctx, orc):
         assert np.array_equal(got, orc.resize_bgr_to_gray(f, dw, dh)), (sw, sh, dw, dh)
 
 
+def test_resize_area_bgr_to_gray_exact(ctx, orc):
+    """The first frame's INTER_AREA resize + BGR2GRAY (ripcurrents.cpp:186): integer factors (2 x 2, 3 x 3,
+    3 x 2), the 1920x1080 -> 640x480 case (3 x 2.25) and ragged factors; bit-exact vs the oracle."""
+    rng = np.random.RandomState(8)
+    for (sw, sh, dw, dh) in ((1280, 960, 640, 480), (1920, 1440, 640, 480), (1920, 960, 640, 480), (1920, 1080, 640, 480),
+                             (1000, 700, 640, 480), (641, 481, 640, 480), (640, 480, 640, 480), (97, 65, 31, 17)):
+        f = rng.randint(0, 256, (sh, sw, 3)).astype(np.uint8)
+        got = ctx.resize_bgr_to_gray(f, dw, dh, interpolation="area").cpu().numpy()
+        assert np.array_equal(got, orc.resize_area_bgr_to_gray(f, dw, dh)), (sw, sh, dw, dh)
+    with pytest.raises(Exception):
+        ctx.resize_bgr_to_gray(np.zeros((240, 320, 3), np.uint8), 640, 480, interpolation="area")    # enlarging
+
+
 def test_display_path_matches_oracle(ctx, orc):
     """streamline_displacement / _total_motion / _ratio / _positions and the float
     HSV->BGR of the flow window, on the slot's streamline field (ripcurrents.cpp:233-273, :405)."""
