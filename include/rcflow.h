@@ -234,6 +234,10 @@ int rcflow_shear_rate_to_color_dev(rc_ctx* ctx, int stream, const float* d_flow_
  * MORPH_ELLIPSE dilate followed by the morphological gradient, fused.  Not in place. */
 int rcflow_create_edges_dev(rc_ctx* ctx, int stream, const uint8_t* d_outmask, size_t mask_step,
                             int w, int h, uint8_t* d_edges, size_t edges_step);
+/* create_output(subframe, outmask) ripcurrents_module.cpp:225-244 (ripcurrents.cpp:487-505): in place,
+ * red channel of the 8UC3 frame := 255 wherever the edge mask is non-zero. */
+int rcflow_create_output_dev(rc_ctx* ctx, int stream, uint8_t* d_subframe_bgr, size_t step,
+                             const uint8_t* d_outmask, size_t mask_step, int w, int h);
 /* resize(frame, subframe, Size(dw,dh), 0, 0, INTER_LINEAR) + cvtColor(COLOR_BGR2GRAY)
  * (ripcurrents.cpp:209-210, main.cpp:258-259): 8UC3 BGR frame in, 8UC1 out. */
 int rcflow_resize_bgr_to_gray_dev(rc_ctx* ctx, int stream, const uint8_t* d_bgr, size_t step,

@@ -77,6 +77,7 @@ SIGNATURES = {
     "rcflow_vector_to_color_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz, C.POINTER(_f)],
     "rcflow_shear_rate_to_color_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz, C.POINTER(_f)],
     "rcflow_create_edges_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz],
+    "rcflow_create_output_dev": [_vp, _i, _vp, _sz, _vp, _sz, _i, _i],
     "rcflow_resize_bgr_to_gray_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz, _i, _i],
     "rcflow_resize_area_bgr_to_gray_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz, _i, _i],
     "rcflow_streamline_display_dev": [_vp, _i, _i, _vp, _sz, C.POINTER(_f)],

@@ -440,6 +440,18 @@ class Context:
                                                 out.stride(0)))
         return out
 
+    def create_output(self, subframe, outmask, stream=0):
+        """create_output(subframe, outmask) ripcurrents_module.cpp:225-244: paints the edge mask into the
+        red channel of the 8UC3 frame, in place when `subframe` is already a device tensor; returns it."""
+        f = self._dev(subframe, torch.uint8).contiguous()
+        m = self._dev(outmask, torch.uint8).contiguous()
+        h, w = m.shape
+        if tuple(f.shape) != (h, w, 3):
+            raise ValueError("subframe must be HxWx3 uint8 of the mask's size")
+        self._bind(stream)
+        check(self._lib.rcflow_create_output_dev(self._h, stream, self._ptr(f), f.stride(0), self._ptr(m), m.stride(0), w, h))
+        return f
+
     def resize_bgr_to_gray(self, frame, dw, dh, stream=0, interpolation="linear"):
         """resize(frame, Size(dw,dh), INTER_LINEAR) + cvtColor(BGR2GRAY) (ripcurrents.cpp:209-210);
         interpolation="area": INTER_AREA, as the reference resizes the first frame (ripcurrents.cpp:186)."""

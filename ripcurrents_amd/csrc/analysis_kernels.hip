@@ -1385,3 +1385,27 @@ extern "C" int rcflow_resize_area_bgr_to_gray_dev(rc_ctx* ctx, int stream, const
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
+
+// create_output(subframe, outmask) ripcurrents_module.cpp:225-244 (ripcurrents.cpp:487-505): the frame the
+// reference writes to its "borders" video -- red channel forced to 255 wherever the edge mask is set.
+__global__ __launch_bounds__(RC_BLOCK) void k_create_output(uint8_t* bgr, size_t step, const uint8_t* mask, size_t mask_step,
+                                                            int w, int h) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    if (mask[(size_t)y * mask_step + x]) bgr[(size_t)y * step + 3 * x + 2] = 255;
+}
+
+extern "C" int rcflow_create_output_dev(rc_ctx* ctx, int stream, uint8_t* d_subframe_bgr, size_t step,
+                                        const uint8_t* d_outmask, size_t mask_step, int w, int h) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    if (!d_subframe_bgr || !d_outmask || w <= 0 || h <= 0 || step < (size_t)w * 3 || mask_step < (size_t)w) {
+        rc_set_error("bad frame / mask arguments");
+        return RC_EINVAL;
+    }
+    RC_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_create_output, dim3((w + 63) / 64, (h + 3) / 4), dim3(RC_BLOCK), 0, s->cur, d_subframe_bgr, step,
+                       d_outmask, mask_step, w, h);
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}

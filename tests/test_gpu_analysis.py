@@ -309,6 +309,17 @@ def test_resize_bgr_to_gray_exact(ctx, orc):
         assert np.array_equal(got, orc.resize_bgr_to_gray(f, dw, dh)), (sw, sh, dw, dh)
 
 
+def test_create_output_paints_the_edges_red(ctx):
+    """create_output (ripcurrents_module.cpp:225-244): pixel.z = 255 where the edge mask is set, rest untouched."""
+    rng = np.random.RandomState(2)
+    for (w, h) in ((640, 480), (33, 7)):
+        frame = rng.randint(0, 255, (h, w, 3)).astype(np.uint8)
+        mask = (rng.rand(h, w) > 0.8).astype(np.uint8) * 255
+        ref = frame.copy()
+        ref[..., 2][mask > 0] = 255
+        assert np.array_equal(ctx.create_output(frame, mask).cpu().numpy(), ref)
+
+
 def test_resize_area_bgr_to_gray_exact(ctx, orc):
     """The first frame's INTER_AREA resize + BGR2GRAY (ripcurrents.cpp:186): integer factors (2 x 2, 3 x 3,
     3 x 2), the 1920x1080 -> 640x480 case (3 x 2.25) and ragged factors; bit-exact vs the oracle."""
