@@ -286,6 +286,55 @@ def test_frame_loop_like_reference(ctx, orc):
     assert np.array_equal(gpt, pt) and np.array_equal(gdist, dist)
 
 
+def test_whole_frame_loop_on_device(ctx, orc):
+    """ripcurrents.cpp:184-511 end to end with nothing but 8-bit images crossing the boundary: decoded
+    BGR frame -> resize (INTER_AREA for the first frame, INTER_LINEAR after) + gray -> flow -> dense
+    advection -> display images -> histogram/thresholds -> classify/accumulate -> edges -> output frame.
+    The oracle follows with the GPU's flow field, so every later product must match exactly."""
+    sw, sh, w, h, T = 960, 540, 320, 240, 4
+    rng = np.random.RandomState(3)
+    gray = synth.surf_clip(sw, sh, T, seed=15)
+    bgr = np.stack([np.clip(gray.astype(np.int32) + d, 0, 255) for d in (-9, 0, 7)], axis=-1).astype(np.uint8)
+    ctx.analysis_reset(w, h)
+    ctx.stream_reset()
+    ost = orc.HistState()
+    pt = np.zeros((h, w, 2), np.float32); dist = np.zeros((h, w), np.float32)
+    acc = np.zeros((h, w, 3), np.float32)
+    framecount = 0
+    for t in range(T):
+        mode = "area" if t == 0 else "linear"                       # ripcurrents.cpp:186 vs :209
+        f1 = ctx.resize_bgr_to_gray(bgr[t], w, h, interpolation=mode)
+        ref_f1 = orc.resize_area_bgr_to_gray(bgr[t], w, h) if t == 0 else orc.resize_bgr_to_gray(bgr[t], w, h)
+        assert np.array_equal(f1.cpu().numpy(), ref_f1)
+        flow = ctx.push_frame(f1)                                    # :215 (+ u_f1.copyTo(u_f2))
+        if flow is None:
+            continue
+        framecount += 1
+        hf = flow.cpu().numpy()
+        ctx.streamline_field(flow, 2.0, 1)                           # :229-231
+        orc.streamline_field(pt, dist, hf, 2.0, 1, ost.UPPER)
+        for which in (0, 1, 2):                                      # :233-257
+            assert np.array_equal(ctx.streamline_display(which)[0].cpu().numpy(), orc.streamline_display(pt, dist, which)[0])
+        st = HistState()
+        ctx.create_histogram(flow, st)                               # :305-366
+        polar = orc.flow_to_polar(hf)
+        orc.create_histogram(polar, ost)
+        outs = ctx.create_flow_accumulate(flow, framecount + 30, want=("outmask", "polar"))   # :376-439
+        wc = np.zeros((h, w, 3), np.float32); acc2 = np.zeros((h, w, 3), np.float32)
+        orc.create_flow(polar, wc, acc2, ost.UPPER, 0.5, 0.2, ost.UPPER2d)
+        out = np.zeros((h, w, 3), np.float32); mask = np.zeros((h, w), np.uint8)
+        orc.create_accumulationbuffer(acc, acc2, out, mask, framecount + 30)
+        assert np.array_equal(ctx.hsv_to_bgr(outs["polar"]).cpu().numpy(), orc.hsv_to_bgr(polar))   # :405
+        edges = ctx.create_edges(outs["outmask"])                     # :477-479
+        ref_edges = orc.create_edges(mask)
+        assert np.array_equal(edges.cpu().numpy(), ref_edges)
+        subframe = rng.randint(0, 255, (h, w, 3)).astype(np.uint8)   # (the resized colour frame)
+        got = ctx.create_output(subframe, edges).cpu().numpy()        # :487-505
+        ref = subframe.copy(); ref[..., 2][ref_edges > 0] = 255
+        assert np.array_equal(got, ref)
+    assert framecount == T - 1
+
+
 def test_create_edges_exact(ctx, orc):
     """5x5 ellipse dilate + morphological gradient on outmask (integer, exact)."""
     rng = np.random.RandomState(5)
