@@ -294,6 +294,19 @@ def test_full_size_1080p_parity(ctx, orc):
     assert st["frac_1e3"] >= 0.99 and st["p50"] <= 1e-4
 
 
+@pytest.mark.parametrize("name,p,minfrac", [("MAIN1119 gaussian win10 it3", MAIN1119, 0.99),
+                                            ("MAIN609 gaussian win20 it3", MAIN609, 0.99),
+                                            ("AND167 box win5 it3 levels3", AND167, 0.99)])
+def test_full_size_1080p_parity_other_call_sites(ctx, orc, name, p, minfrac):
+    """The other reference parameter sets at 1080p against the oracle (8 oracle threads, a few seconds each)."""
+    clip = synth.surf_clip(1920, 1080, 2, seed=77)
+    ref = orc.farneback(clip[0], clip[1], p["pyr_scale"], p["levels"], p["winsize"], p["iterations"], p["poly_n"],
+                        p["poly_sigma"], p["flags"], nthreads=8)
+    got = ctx.calcOpticalFlowFarneback(clip[0], clip[1], None, **p)
+    st = _report("1080p " + name, got, ref)
+    assert st["frac_1e3"] >= minfrac and st["p50"] <= 1e-4
+
+
 def test_4k_five_scales_properties(ctx):
     """BASELINE config 3 (3840x2160, levels=4): size-independent properties instead of the
     oracle: zero motion -> zero interior flow; flipping both frames left-right mirrors the flow."""
