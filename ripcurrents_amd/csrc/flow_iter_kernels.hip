@@ -439,6 +439,175 @@ static void launch_iter_big(RcIterArgs a, int pairs, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------
+// Large Gaussian windows (winsize 10 / 20 x 3 iterations: main.cpp:609,961,1119,1481), one iteration
+// per launch.  A block owns a strip of 64 output columns and sweeps a segment of a.th rows
+// downwards, CH = 8 rows per step, with the matrices of the last CH + 2m rows in an LDS ring:
+// every matrix row is evaluated once per strip (the tile kernel above re-evaluates the 2m halo
+// rows of every 32-row tile: 2.1x the pixels at m = 10, here (64 + 2m)/64 x (rows + 2m)/rows).
+//   a  matrices of the CH new rows (64 + 2m columns, global gathers, several pixels in flight)
+//   b  vertical pass: item = (channel, column), register window of CH + 2m ring rows -> V
+//   c1 horizontal pass: item = (channel, row, 4 pixels), 16-byte LDS reads of the V row
+//   c2 solve + store.  The per-channel sums travel from c1 to c2 through the ring rows that
+//      died with this step (the oldest CH), so the block needs no third buffer.
+// Operation order of every sum is the tile kernel's (= optflow.cpp's): same bits.
+template <int M_>
+struct RcSweep {
+    static constexpr int TW = 64, CH = 8, MW = TW + 2 * M_, MP = MW | 1;
+    static constexpr int RING = ((CH + 2 * M_ + CH - 1) / CH) * CH;     // 32 rows (m = 10), 24 (m = 5)
+    static constexpr int NQ = (4 + 2 * M_ + 3) / 4;                     // float4s under a 4-pixel group's taps
+    static constexpr int VP = (MW + 3) & ~3;
+    static_assert(4 * 15 + 4 * NQ <= VP, "V row holds the last group's taps");
+    static_assert(CH * TW <= CH * MP, "c1 -> c2 sums fit the dead ring rows of one plane");
+    static constexpr size_t LDS = sizeof(float) * (5 * RING * MP + 5 * CH * VP);
+};
+
+template <int M_, int NT, int START>
+__device__ __forceinline__ void rc_sweep_bc(const RcIterArgs& a, float* ring, float* V, int tid, int tx0, int Y,
+                                            int yend, char* fout) {
+    using S = RcSweep<M_>;
+    constexpr int CH = S::CH, MW = S::MW, MP = S::MP, RING = S::RING, VP = S::VP, NQ = S::NQ, TW = S::TW;
+    // ---- b: vertical pass
+    if (!(a.ablate & 4194304))
+    for (int idx = tid; idx < 5 * MW; idx += NT) {
+        const int c = idx / MW, col = idx - c * MW;
+        const float* mc = ring + c * RING * MP + col;
+        float v[CH + 2 * M_];
+#pragma unroll
+        for (int r = 0; r < CH + 2 * M_; r++) v[r] = mc[((START + r) % RING) * MP];
+        float* vo = V + c * CH * VP + col;
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            float s = v[j + M_] * a.win.k[0];
+#pragma unroll
+            for (int i = 1; i <= M_; i++) s += (v[j + M_ + i] + v[j + M_ - i]) * a.win.k[i];
+            vo[j * VP] = s;
+        }
+    }
+    __syncthreads();
+    // ---- c1: horizontal pass, 4 pixels per item
+    float* G = ring + START * MP;               // plane c at + c * RING * MP: CH * TW floats each
+    if (!(a.ablate & 4194304))
+    for (int idx = tid; idx < 5 * CH * (TW / 4); idx += NT) {
+        const int g4 = idx % (TW / 4), row = (idx / (TW / 4)) % CH, c = idx / (CH * (TW / 4));
+        const float4* vp = (const float4*)(V + c * CH * VP + row * VP + 4 * g4);
+        float v[4 * NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            float4 t = vp[q];
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+        float o[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            float s = v[M_ + p] * a.win.k[0];
+#pragma unroll
+            for (int i = 1; i <= M_; i++) s += a.win.k[i] * (v[M_ + p - i] + v[M_ + p + i]);
+            o[p] = s;
+        }
+        *(float4*)(G + c * RING * MP + row * TW + 4 * g4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+    // ---- c2: solve
+    for (int px = tid; px < CH * TW; px += NT) {
+        const int row = px / TW, lx = px - row * TW;
+        const int gx = tx0 + lx, gy = Y + row;
+        double g[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) g[c] = G[c * RING * MP + px];
+        if (gx < a.w && gy < yend) *(float2*)(fout + (size_t)gy * a.fout_step + (size_t)gx * 8) = rc_solve(g);
+    }
+    __syncthreads();
+}
+
+template <int M_, int NT, int BATCH>
+__global__ __launch_bounds__(NT) void k_flow_iter_sweep(RcIterArgs a) {
+    using S = RcSweep<M_>;
+    constexpr int CH = S::CH, MW = S::MW, MP = S::MP, RING = S::RING, TW = S::TW;
+    extern __shared__ __align__(16) float smf[];
+    float* ring = smf;                          // [5][RING][MP]
+    float* V = smf + 5 * RING * MP;             // [5][CH][VP]
+    const int tid = threadIdx.x;
+    const int z = blockIdx.y;
+    const int strip = blockIdx.x % a.tiles_x, seg = blockIdx.x / a.tiles_x;
+    const int tx0 = strip * TW, y0 = seg * a.th;
+    const int w = a.w, h = a.h;
+    const int yend = min(y0 + a.th, h);
+    const size_t s0 = (size_t)((a.slot0 + z * a.zstep) % a.nslots) * a.R_slot_stride;
+    const size_t s1 = (size_t)((a.slot1 + z * a.zstep) % a.nslots) * a.R_slot_stride;
+    const float4* RA0 = a.RA + s0;  const float* RB0 = a.RB + s0;
+    const float4* RA1 = a.RA + s1;  const float* RB1 = a.RB + s1;
+    const float2* fin = a.fin ? a.fin + (size_t)z * a.fin_pair_stride : nullptr;
+    char* fout = a.fout + (size_t)z * a.fout_pair_stride;
+
+    // ---- a: matrices of image rows r0 .. r0 + nrows - 1 (replicated outside the image) -> ring
+    auto matrices_rows = [&](int r0, int nrows) {
+        if (a.ablate & 2097152) return;
+        const int n = nrows * MW;
+        for (int base = tid; base < n; base += NT * BATCH) {
+            float2 d[BATCH];
+            int gxs[BATCH], gys[BATCH];
+#pragma unroll
+            for (int q = 0; q < BATCH; q++) {
+                const int idx = min(base + q * NT, n - 1);
+                const int j = idx / MW, lx = idx - j * MW;
+                gxs[q] = rc_clampi(tx0 - M_ + lx, 0, w - 1);
+                gys[q] = rc_clampi(r0 + j, 0, h - 1);
+                d[q] = rc_flow_in(a, fin, gxs[q], gys[q]);
+            }
+            RcM5 v[BATCH];
+#pragma unroll
+            for (int q = 0; q < BATCH; q++)
+                v[q] = rc_matrices(RA0, RB0, RA1, RB1, gxs[q], gys[q], w, h, d[q].x, d[q].y);
+#pragma unroll
+            for (int q = 0; q < BATCH; q++) {
+                const int idx = base + q * NT;
+                if (idx < n) {
+                    const int j = idx / MW, lx = idx - j * MW;
+                    const int slot = (r0 + j - (y0 - M_)) % RING;
+                    float* mp = ring + slot * MP + lx;
+                    mp[0] = v[q].m0;
+                    mp[RING * MP] = v[q].m1;
+                    mp[2 * RING * MP] = v[q].m2;
+                    mp[3 * RING * MP] = v[q].m3;
+                    mp[4 * RING * MP] = v[q].m4;
+                }
+            }
+        }
+    };
+    matrices_rows(y0 - M_, 2 * M_);
+    const int nsteps = (yend - y0 + CH - 1) / CH;
+    for (int s = 0; s < nsteps; s++) {
+        matrices_rows(y0 + M_ + CH * s, CH);
+        __syncthreads();
+        const int Y = y0 + CH * s;
+        switch (s % (RING / CH)) {
+            case 0: rc_sweep_bc<M_, NT, 0>(a, ring, V, tid, tx0, Y, yend, fout); break;
+            case 1: rc_sweep_bc<M_, NT, CH>(a, ring, V, tid, tx0, Y, yend, fout); break;
+            case 2: rc_sweep_bc<M_, NT, 2 * CH>(a, ring, V, tid, tx0, Y, yend, fout); break;
+            default: if constexpr (RING / CH > 3) rc_sweep_bc<M_, NT, 3 * CH>(a, ring, V, tid, tx0, Y, yend, fout); break;
+        }
+    }
+}
+
+template <int M, int NT, int BATCH>
+static void launch_iter_sweep(RcIterArgs a, int pairs, hipStream_t s) {
+    using S = RcSweep<M>;
+    static_assert(S::RING / S::CH <= 4, "step dispatch covers four ring phases");
+    RC_ALLOW_LDS((k_flow_iter_sweep<M, NT, BATCH>), S::LDS);
+    a.tw = S::TW;
+    a.tiles_x = (a.w + S::TW - 1) / S::TW;
+    // segment height: as tall as still leaves every CU a few blocks
+    const int want = (a.ablate & 524288) ? 2 * 512 : ((a.ablate & 1048576) ? 8 * 512 : 4 * 512);
+    int segs = (want + a.tiles_x * pairs - 1) / (a.tiles_x * pairs);
+    int rs = (a.h + segs - 1) / segs;
+    rs = ((rs + S::CH - 1) / S::CH) * S::CH;
+    if (rs < 32) rs = 32;
+    a.th = rs;
+    a.tiles_y = (a.h + rs - 1) / rs;
+    hipLaunchKernelGGL((k_flow_iter_sweep<M, NT, BATCH>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(NT), S::LDS, s, a);
+}
+
+// ------------------------------------------------------------------------------------
 // The 3x3-window kernel (winsize 3: ripcurrents.cpp:215, main.cpp:264): 64x16 tile,
 // 512 threads.  Latency is what bounds this stage, so the memory phases are explicit: every
 // thread first has the flow of its (at most three) tile+halo pixels in flight, then all
@@ -1233,6 +1402,16 @@ void rc_launch_flow_iter(const RcIterArgs& a, int pairs, hipStream_t s) {
     if (a.solve && !(a.ablate & 8192)) {
         // 16 waves per CU: LDS 50 KB (m = 2) -> 3 blocks x 512 threads, 64 KB (m = 5) -> 2 x 1024, 142 KB (m = 10, 64 x 32 tile) -> 1 x 1024
         if (m == 2) { g ? launch_iter_big<2, 1, 512>(a, pairs, s) : launch_iter_big<2, 0, 512>(a, pairs, s); return; }
+        // Gaussian winsize 10 / 20: the strip-sweep kernel once the launch is big enough to fill the GPU
+        // with strips (measured crossover, scripts/exp21.py); bit-identical to the tile kernel
+        // (ablate 65536 forces the tile kernel, 8388608 the sweep)
+        const long long work = (long long)a.w * a.h * pairs;
+        if (g && (m == 5 || m == 10) && !(a.ablate & 65536) &&
+            ((a.ablate & 8388608) || work >= (m == 10 ? 900000ll : 8000000ll))) {
+            if (a.ablate & 131072) { m == 5 ? launch_iter_sweep<5, 512, 2>(a, pairs, s) : launch_iter_sweep<10, 512, 2>(a, pairs, s); }
+            else { m == 5 ? launch_iter_sweep<5, 1024, 1>(a, pairs, s) : launch_iter_sweep<10, 1024, 1>(a, pairs, s); }
+            return;
+        }
         if (m == 5) { g ? launch_iter_big<5, 1, 1024>(a, pairs, s) : launch_iter_big<5, 0, 1024>(a, pairs, s); return; }   // (64 wide: 6 % slower, one block per CU)
         if (m == 10) {
             if (a.ablate & 32768) { g ? launch_iter_big<10, 1, 1024>(a, pairs, s) : launch_iter_big<10, 0, 1024>(a, pairs, s); }

@@ -157,6 +157,47 @@ def test_flow_iteration_stage(ctx, orc, winsize, flags):
     assert (np.abs(got0 - ref0).max(-1) <= 1e-3).mean() >= 0.999
 
 
+@pytest.mark.parametrize("winsize", [10, 20])
+def test_flow_iteration_stage_sweep_kernel(ctx, orc, winsize):
+    """The strip-sweep kernel (large launches of the Gaussian winsize 10 / 20 call sites) forced on a
+    small stage input: same oracle comparison as the tile kernel, and the same bits as the tile kernel."""
+    w, h = 333, 217
+    clip = synth.surf_clip(w, h, 2, seed=22)
+    I0 = orc.pyr_level(clip[0], 0.0, 3, w, h)
+    I1 = orc.pyr_level(clip[1], 0.0, 3, w, h)
+    R0, R1 = orc.polyexp(I0), orc.polyexp(I1)
+    fin = (np.random.RandomState(2).randn(h, w, 2) * 1.5).astype(np.float32)
+    M = orc.update_matrices(R0, R1, fin)
+    ref = fin.copy()
+    orc.update_flow(R0, R1, ref, M, winsize, False, True)
+    try:
+        ctx.set_option("ablate", 65536)
+        tile = ctx.stage_flow_iter(R0, R1, fin, winsize, 256).cpu().numpy()
+        ctx.set_option("ablate", 8388608)
+        got = ctx.stage_flow_iter(R0, R1, fin, winsize, 256).cpu().numpy()
+    finally:
+        ctx.set_option("ablate", 0)
+    assert _report("flow_iter sweep win=%d" % winsize, got, ref)["frac_1e3"] >= 0.999
+    assert np.array_equal(got, tile)
+
+
+@pytest.mark.parametrize("size,npairs", [((333, 251), 3), ((97, 70), 2), ((64, 19), 1), ((1000, 9), 1)])
+def test_sweep_kernel_whole_path_identical_to_tile_kernel(ctx, size, npairs):
+    """MAIN609 / MAIN1119 through farneback_clip with either kernel forced: identical flow fields
+    (ragged strips, segments shorter than the window, images lower than the window radius)."""
+    w, h = size
+    clip = synth.surf_clip(w, h, npairs + 1, seed=9)
+    try:
+        for p in (MAIN609, MAIN1119):
+            ctx.set_option("ablate", 65536)
+            a = ctx.farneback_clip(clip, **p).cpu().numpy()
+            ctx.set_option("ablate", 8388608)
+            b = ctx.farneback_clip(clip, **p).cpu().numpy()
+            assert np.isfinite(a).all() and np.array_equal(a, b)
+    finally:
+        ctx.set_option("ablate", 0)
+
+
 @pytest.mark.parametrize("name,p,size,minfrac", [
     ("RC215 640x480", RC215, (640, 480), 0.99),
     ("MAIN264 gaussian win3", MAIN264, (640, 480), 0.85),
