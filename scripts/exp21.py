@@ -4,9 +4,9 @@ sys.path.insert(0, '.')
 from ripcurrents_amd import synth
 from ripcurrents_amd.api import Context
 variants = [("tile", 65536), ("sweep", 0)] + [(a.split("=")[0], int(a.split("=")[1])) for a in sys.argv[1:]]
-for (W, H) in [(1920, 1080), (1280, 720), (640, 480), (333, 217)]:
+for (W, H) in [(1920, 1080)]:
     ctx = Context(W, H)
-    for npairs in (1, 4, 16):
+    for npairs in (16,):
         frames = synth.surf_clip(W, H, npairs + 1, device=torch.device("cuda"))
         for ws in (10, 20):
             P = dict(pyr_scale=0.5, levels=2, winsize=ws, iterations=3, poly_n=15, poly_sigma=1.2, flags=256)
