@@ -467,7 +467,6 @@ __device__ __forceinline__ void rc_sweep_bc(const RcIterArgs& a, float* ring, fl
     using S = RcSweep<M_>;
     constexpr int CH = S::CH, MW = S::MW, MP = S::MP, RING = S::RING, VP = S::VP, NQ = S::NQ, TW = S::TW;
     // ---- b: vertical pass
-    if (!(a.ablate & 4194304))
     for (int idx = tid; idx < 5 * MW; idx += NT) {
         const int c = idx / MW, col = idx - c * MW;
         const float* mc = ring + c * RING * MP + col;
@@ -486,7 +485,6 @@ __device__ __forceinline__ void rc_sweep_bc(const RcIterArgs& a, float* ring, fl
     __syncthreads();
     // ---- c1: horizontal pass, 4 pixels per item
     float* G = ring + START * MP;               // plane c at + c * RING * MP: CH * TW floats each
-    if (!(a.ablate & 4194304))
     for (int idx = tid; idx < 5 * CH * (TW / 4); idx += NT) {
         const int g4 = idx % (TW / 4), row = (idx / (TW / 4)) % CH, c = idx / (CH * (TW / 4));
         const float4* vp = (const float4*)(V + c * CH * VP + row * VP + 4 * g4);
@@ -541,7 +539,6 @@ __global__ __launch_bounds__(NT) void k_flow_iter_sweep(RcIterArgs a) {
 
     // ---- a: matrices of image rows r0 .. r0 + nrows - 1 (replicated outside the image) -> ring
     auto matrices_rows = [&](int r0, int nrows) {
-        if (a.ablate & 2097152) return;
         const int n = nrows * MW;
         for (int base = tid; base < n; base += NT * BATCH) {
             float2 d[BATCH];
@@ -597,7 +594,7 @@ static void launch_iter_sweep(RcIterArgs a, int pairs, hipStream_t s) {
     a.tw = S::TW;
     a.tiles_x = (a.w + S::TW - 1) / S::TW;
     // segment height: as tall as still leaves every CU a few blocks
-    const int want = (a.ablate & 524288) ? 2 * 512 : ((a.ablate & 1048576) ? 8 * 512 : 4 * 512);
+    const int want = 4 * 512;
     int segs = (want + a.tiles_x * pairs - 1) / (a.tiles_x * pairs);
     int rs = (a.h + segs - 1) / segs;
     rs = ((rs + S::CH - 1) / S::CH) * S::CH;
@@ -632,7 +629,7 @@ __global__ __launch_bounds__(RC_W3_THREADS) void k_flow_iter_w3(RcIterArgs a) {
     const float2* __restrict__ fin = a.fin + (size_t)z * a.fin_pair_stride;
     char* fout = a.fout + (size_t)z * a.fout_pair_stride;
 
-    if (a.ablate & 8) {              // ablation: empty block
+    if (a.ablate & RC_ABL_EMPTY_BLOCKS) {              // ablation: empty block
         if (tid == 9999) *(float*)fout = 1.f;
         return;
     }
@@ -704,7 +701,7 @@ __global__ __launch_bounds__(RC_W3_THREADS) void k_flow_iter_w3(RcIterArgs a) {
         }
     }
     __syncthreads();
-    if (a.ablate & 4) {              // ablation: no window / solve / store
+    if (a.ablate & RC_ABL_NO_WINDOW) {              // ablation: no window / solve / store
         if (Ms[tid] == 12345.678f) *(float*)fout = 1.f;
         return;
     }
@@ -940,7 +937,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_iter2_w3(RcIterArgs a) {
     }
     __syncthreads();
     RC_STAMP(3);
-    if (a.ablate & 1) {              // ablation: stage A only
+    if (a.ablate & RC_ABL_STAGE_A_ONLY) {              // ablation: stage A only
         if (Ms[tid] == 12345.678f) *(float*)fout = 1.f;
         return;
     }
@@ -1017,7 +1014,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_iter2_w3(RcIterArgs a) {
 #undef RC_GY
     __syncthreads();
     RC_STAMP(5);
-    if (a.ablate & 4) {              // ablation: no final window/solve/store
+    if (a.ablate & RC_ABL_NO_WINDOW) {              // ablation: no final window/solve/store
         if (Ms[tid] == 12345.678f) *(float*)fout = 1.f;
         return;
     }
@@ -1326,12 +1323,12 @@ static void launch_rr_t(RcIterArgs a, int pairs, hipStream_t s) {
 
 template <int IN_MODE, int G>
 static void launch_w3x2(RcIterArgs a, int pairs, hipStream_t s) {
-    if (a.ablate & 64) launch_w3x2_t<IN_MODE, G, 32, 16, 256, 4>(a, pairs, s);   // LDS-resident M (first form)
-    else if (a.ablate & 128) launch_rr_t<IN_MODE, G, 3, 4, 5>(a, pairs, s);     // 28x20 tile, 5 blocks per CU
-    else if (a.ablate & 256) launch_rr_t<IN_MODE, G, 2, 4, 6>(a, pairs, s);     // 28x12 tile, 6 blocks per CU
-    else if (a.ablate & 512) launch_rr_t<IN_MODE, G, 4, 3, 2, 64>(a, pairs, s);  // 60x28 tile, 512 threads, 2 blocks per CU
-    else if (a.ablate & 1024) launch_rr_t<IN_MODE, G, 2, 3, 4, 32, 16>(a, pairs, s);  // 28x28 tile, 512 threads x 2 rows
-    else if (a.ablate & 16384) launch_rr_t<IN_MODE, G, 2, 3, 8, 32, 16>(a, pairs, s); // same, registers capped for 8 waves per SIMD
+    if (a.ablate & RC_ABL_W3X2_LDS_M) launch_w3x2_t<IN_MODE, G, 32, 16, 256, 4>(a, pairs, s);   // LDS-resident M (first form)
+    else if (a.ablate & RC_ABL_RR_28X20) launch_rr_t<IN_MODE, G, 3, 4, 5>(a, pairs, s);     // 28x20 tile, 5 blocks per CU
+    else if (a.ablate & RC_ABL_RR_28X12) launch_rr_t<IN_MODE, G, 2, 4, 6>(a, pairs, s);     // 28x12 tile, 6 blocks per CU
+    else if (a.ablate & RC_ABL_RR_60X28) launch_rr_t<IN_MODE, G, 4, 3, 2, 64>(a, pairs, s);  // 60x28 tile, 512 threads, 2 blocks per CU
+    else if (a.ablate & RC_ABL_RR_512T) launch_rr_t<IN_MODE, G, 2, 3, 4, 32, 16>(a, pairs, s);  // 28x28 tile, 512 threads x 2 rows
+    else if (a.ablate & RC_ABL_RR_512T_8W) launch_rr_t<IN_MODE, G, 2, 3, 8, 32, 16>(a, pairs, s); // same, registers capped for 8 waves per SIMD
     else {
         // A launch of fewer blocks than the GPU holds at once (1024 = 256 CUs x 4) lasts one block's
         // lifetime: shorter tiles then finish sooner (frame-at-a-time calls, coarse scales).  Same bits.
@@ -1399,22 +1396,22 @@ void rc_launch_flow_iter(const RcIterArgs& a, int pairs, hipStream_t s) {
         return;
     }
     if (m == 1) { g ? launch_iter_t<64, 16, 1, 1>(a, pairs, s) : launch_iter_t<64, 16, 1, 0>(a, pairs, s); return; }
-    if (a.solve && !(a.ablate & 8192)) {
+    if (a.solve && !(a.ablate & RC_ABL_GENERIC_WINDOW)) {
         // 16 waves per CU: LDS 50 KB (m = 2) -> 3 blocks x 512 threads, 64 KB (m = 5) -> 2 x 1024, 142 KB (m = 10, 64 x 32 tile) -> 1 x 1024
         if (m == 2) { g ? launch_iter_big<2, 1, 512>(a, pairs, s) : launch_iter_big<2, 0, 512>(a, pairs, s); return; }
         // Gaussian winsize 10 / 20: the strip-sweep kernel once the launch is big enough to fill the GPU
         // with strips (measured crossover, scripts/exp21.py); bit-identical to the tile kernel
-        // (ablate 65536 forces the tile kernel, 8388608 the sweep)
+        // (RC_ABL_TILE_WINDOW forces the tile kernel, RC_ABL_FORCE_SWEEP the sweep)
         const long long work = (long long)a.w * a.h * pairs;
-        if (g && (m == 5 || m == 10) && !(a.ablate & 65536) &&
-            ((a.ablate & 8388608) || work >= (m == 10 ? 900000ll : 8000000ll))) {
-            if (a.ablate & 131072) { m == 5 ? launch_iter_sweep<5, 512, 2>(a, pairs, s) : launch_iter_sweep<10, 512, 2>(a, pairs, s); }
+        if (g && (m == 5 || m == 10) && !(a.ablate & RC_ABL_TILE_WINDOW) &&
+            ((a.ablate & RC_ABL_FORCE_SWEEP) || work >= (m == 10 ? 900000ll : 8000000ll))) {
+            if (a.ablate & RC_ABL_SWEEP_512T) { m == 5 ? launch_iter_sweep<5, 512, 2>(a, pairs, s) : launch_iter_sweep<10, 512, 2>(a, pairs, s); }
             else { m == 5 ? launch_iter_sweep<5, 1024, 1>(a, pairs, s) : launch_iter_sweep<10, 1024, 1>(a, pairs, s); }
             return;
         }
         if (m == 5) { g ? launch_iter_big<5, 1, 1024>(a, pairs, s) : launch_iter_big<5, 0, 1024>(a, pairs, s); return; }   // (64 wide: 6 % slower, one block per CU)
         if (m == 10) {
-            if (a.ablate & 32768) { g ? launch_iter_big<10, 1, 1024>(a, pairs, s) : launch_iter_big<10, 0, 1024>(a, pairs, s); }
+            if (a.ablate & RC_ABL_BIG_32WIDE) { g ? launch_iter_big<10, 1, 1024>(a, pairs, s) : launch_iter_big<10, 0, 1024>(a, pairs, s); }
             else { g ? launch_iter_big<10, 1, 1024, 64>(a, pairs, s) : launch_iter_big<10, 0, 1024, 64>(a, pairs, s); }
             return;
         }

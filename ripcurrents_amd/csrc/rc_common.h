@@ -58,7 +58,7 @@ struct RcPyrArgs {
     int ksize;
     const float* kern;        // device, ksize floats
     int tw, th, reg_wp, reg_hmax;
-    int direct;               // diagnostic (ablate bit 12): the earlier per-pixel / LDS-staged kernels
+    int direct;               // diagnostic (RC_ABL_PYR_STAGED): the earlier per-pixel / LDS-staged kernels
 };
 
 struct RcPolyArgs {
@@ -75,6 +75,27 @@ struct RcPolyArgs {
     int no_fast_u8;           // diagnostic: byte-wise staging for every tile
     int valu_vertical;        // option "poly_mfma" = 0: vertical pass on the VALU instead of the matrix cores
     RcPolyK pk;
+};
+
+// Option "ablate": earlier kernel forms and timing-only cuts kept for same-box A/B runs (0 in production).
+// The first three change results (timing only); every other bit selects a bit-identical alternative.
+enum RcAblate : int {
+    RC_ABL_STAGE_A_ONLY = 1,         // winsize-3 kernels: stop after the first matrices stage
+    RC_ABL_NO_WINDOW = 4,            // skip window / solve / store
+    RC_ABL_EMPTY_BLOCKS = 8,         // launch cost only
+    RC_ABL_W3X2_LDS_M = 64,          // fused pair with M in LDS (first form)
+    RC_ABL_RR_28X20 = 128,           // register-row kernel: 28x20 tile, 5 blocks per CU
+    RC_ABL_RR_28X12 = 256,           //   28x12 tile, 6 blocks per CU
+    RC_ABL_RR_60X28 = 512,           //   60x28 tile, 512 threads
+    RC_ABL_RR_512T = 1024,           //   28x28 tile, 512 threads x 2 rows
+    RC_ABL_NO_FAST_U8 = 2048,        // expansion at scale 0: per-byte staging instead of dwords + v_perm
+    RC_ABL_PYR_STAGED = 4096,        // pyramid: per-pixel / LDS-staged kernels
+    RC_ABL_GENERIC_WINDOW = 8192,    // windows 5 / 10 / 20: runtime-sized generic kernel
+    RC_ABL_RR_512T_8W = 16384,       // register-row kernel, 512 threads, registers capped for 8 waves per SIMD
+    RC_ABL_BIG_32WIDE = 32768,       // winsize 20 tile kernel: 32-wide tiles
+    RC_ABL_TILE_WINDOW = 65536,      // Gaussian winsize 10 / 20: tile kernel even for large launches
+    RC_ABL_SWEEP_512T = 131072,      // strip-sweep kernel with 512 threads
+    RC_ABL_FORCE_SWEEP = 8388608,    // strip-sweep kernel even for small launches
 };
 
 struct RcIterArgs {

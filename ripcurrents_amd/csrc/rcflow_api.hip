@@ -530,7 +530,7 @@ static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t fr
         memset(&q, 0, sizeof(q));
         q.RA = (float4*)s.RA[k].p; q.RB = (float*)s.RB[k].p; q.R_slot_stride = n;
         q.slot0 = dslot0; q.nslots = pl.nslots; q.zstep = zstep; q.w = L.w; q.h = L.h; q.pk = pl.pk;
-        q.tile_h = ctx->poly_tile_h; q.no_fast_u8 = (ctx->ablate >> 11) & 1; q.valu_vertical = !ctx->poly_mfma;
+        q.tile_h = ctx->poly_tile_h; q.no_fast_u8 = (ctx->ablate & RC_ABL_NO_FAST_U8) != 0; q.valu_vertical = !ctx->poly_mfma;
         if (k == 0) {
             // scale 0: pyramid (3x3 blur, identity resize) fused into the expansion
             q.src8 = d_src; q.src8_step = step; q.src8_frame_stride = frame_stride;
@@ -546,7 +546,7 @@ static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t fr
         p.w = L.w; p.h = L.h; p.scale_x = L.scale_x; p.scale_y = L.scale_y;
         p.ksize = L.ksize; p.kern = (const float*)s.kern.p + pl.kern_off[k];
         p.tw = L.pyr_tw; p.th = L.pyr_th; p.reg_wp = L.pyr_reg_w; p.reg_hmax = L.pyr_reg_h;
-        p.direct = (ctx->ablate >> 12) & 1;
+        p.direct = (ctx->ablate & RC_ABL_PYR_STAGED) != 0;
     }
     auto npx = [&](int k) { return (double)pl.lv[k].w * pl.lv[k].h; };
     // A frame or two per call (the frame-at-a-time loop, two-image calls): the scales' grids are each
@@ -922,7 +922,7 @@ extern "C" int rcflow_stage_pyr_level_dev(rc_ctx* ctx, int stream, const uint8_t
     pa.w = L.w; pa.h = L.h; pa.scale_x = L.scale_x; pa.scale_y = L.scale_y;
     pa.ksize = L.ksize; pa.kern = (const float*)s->stage_f32[0].p;
     pa.tw = L.pyr_tw; pa.th = L.pyr_th; pa.reg_wp = L.pyr_reg_w; pa.reg_hmax = L.pyr_reg_h;
-    pa.direct = (ctx->ablate >> 12) & 1;
+    pa.direct = (ctx->ablate & RC_ABL_PYR_STAGED) != 0;
     rc_launch_pyr(pa, 1, L.pyr_lds, s->cur);
     RC_HIP(hipGetLastError());
     return RC_OK;
