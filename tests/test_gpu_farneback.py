@@ -399,6 +399,34 @@ def test_4k_config3_advection_on_gpu_flow(ctx, orc):
             assert np.array_equal(np.asarray(sl.vertices, np.float32), overts[i][:state[i][0]])
 
 
+SWEEP = [
+    dict(pyr_scale=0.8, levels=3, winsize=15, iterations=3, poly_n=5, poly_sigma=1.1, flags=0),      # OpenCV sample defaults
+    dict(pyr_scale=0.8, levels=3, winsize=15, iterations=3, poly_n=7, poly_sigma=1.5, flags=256),
+    dict(pyr_scale=0.75, levels=4, winsize=7, iterations=2, poly_n=7, poly_sigma=1.5, flags=0),
+    dict(pyr_scale=0.6, levels=5, winsize=9, iterations=1, poly_n=5, poly_sigma=1.1, flags=256),
+    dict(pyr_scale=0.5, levels=1, winsize=25, iterations=4, poly_n=15, poly_sigma=1.2, flags=256),
+    dict(pyr_scale=0.5, levels=0, winsize=3, iterations=1, poly_n=15, poly_sigma=1.2, flags=0),      # one scale, one iteration
+    dict(pyr_scale=0.5, levels=3, winsize=4, iterations=3, poly_n=5, poly_sigma=1.1, flags=0),       # even window
+    dict(pyr_scale=0.3, levels=2, winsize=11, iterations=2, poly_n=7, poly_sigma=1.5, flags=0),
+    dict(pyr_scale=0.9, levels=6, winsize=5, iterations=2, poly_n=5, poly_sigma=1.1, flags=256),
+    dict(pyr_scale=0.5, levels=2, winsize=21, iterations=2, poly_n=10, poly_sigma=2.0, flags=0),
+]
+
+
+@pytest.mark.parametrize("i", range(len(SWEEP)))
+def test_parameter_sweep_beyond_the_reference_call_sites(ctx, orc, i):
+    """The drop-in signature takes any parameter set, not only the five the reference uses: other
+    pyramid ratios (non-integer level sizes), level counts, window sizes (generic kernels), expansion
+    sizes and iteration counts, against the oracle at 230x170."""
+    p = SWEEP[i]
+    clip = synth.surf_clip(230, 170, 2, seed=100 + i)
+    ref = _oracle_flow(orc, clip[0], clip[1], p)
+    got = ctx.calcOpticalFlowFarneback(clip[0], clip[1], None, **p)
+    st = _report("sweep %d %s" % (i, p), got, ref)
+    assert np.isfinite(got).all()
+    assert st["frac_1e3"] >= 0.97 and st["p50"] <= 2e-4
+
+
 def test_error_codes(ctx):
     from ripcurrents_amd import RcflowError
     a = np.zeros((64, 64), np.uint8)
