@@ -28,6 +28,34 @@ def allreduce_hist_words(words, group=None):
     return g
 
 
+class PendingHistSum:
+    """An all-reduce of the histogram words in flight (allreduce_hist_words_async).  wait()
+    orders the caller's stream after the collective (RCCL: a stream wait, the host does not
+    block; gloo: the host blocks) and returns the summed words."""
+
+    def __init__(self, work, words):
+        self._work, self._words = work, words
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._words
+
+
+def allreduce_hist_words_async(words, group=None):
+    """Start the sum of the 1887-word block over all ranks and return a PendingHistSum: the
+    collective (7.5 KB, latency-bound) then runs on RCCL's stream beside the next batch's flow
+    kernels, and the global thresholds are derived when the caller comes back for it."""
+    if words.numel() != HIST_WORDS or words.dtype != torch.int32:
+        raise ValueError("expected %d int32 histogram words" % HIST_WORDS)
+    g = words.clone()
+    work = None
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return PendingHistSum(work, g)
+
+
 def split_hist_words(words):
     """hist[50], hist2d[36][50], histsum, histsum2d[36] views of a words block."""
     w = words.cpu().numpy() if isinstance(words, torch.Tensor) else words

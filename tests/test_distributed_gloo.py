@@ -39,6 +39,10 @@ def _worker(rank, world, port, out_dir):
     words = torch.from_numpy(_words_of(st))
     g = allreduce_hist_words(words)
     assert torch.equal(words, torch.from_numpy(_words_of(st)))     # the rank's own counters are untouched
+    from ripcurrents_amd.distributed import allreduce_hist_words_async
+    pend = allreduce_hist_words_async(words)                       # the form bench.py overlaps with the next step
+    assert torch.equal(pend.wait(), g) and torch.equal(pend.wait(), g)
+    assert torch.equal(words, torch.from_numpy(_words_of(st)))
     hist, hist2d, histsum, histsum2d = split_hist_words(g)
     gs = oracle.HistState()
     gs.hist[:] = hist; gs.hist2d[:] = hist2d; gs.histsum.value = histsum; gs.histsum2d[:] = histsum2d
@@ -68,6 +72,8 @@ def test_allreduce_is_identity_without_a_process_group():
     from ripcurrents_amd._lib import HIST_WORDS
     w = torch.arange(HIST_WORDS, dtype=torch.int32)
     g = allreduce_hist_words(w)
+    from ripcurrents_amd.distributed import allreduce_hist_words_async
+    assert torch.equal(allreduce_hist_words_async(w).wait(), g)
     assert torch.equal(g, w) and g.data_ptr() != w.data_ptr()
     with pytest.raises(ValueError):
         allreduce_hist_words(torch.zeros(5, dtype=torch.int32))
