@@ -428,14 +428,128 @@ void rc_launch_pyr(const RcPyrArgs& a, int frames, size_t lds, hipStream_t s) {
 // window.  A per-tile constant is subtracted before the sums and its exact contribution
 // (pk.kdc) is added back in the double-precision epilogue: the yy/xx coefficients are
 // differences of O(100) sums, and this keeps them at fp32's best.
+// PYR = 1 (with U8): the block also writes its part of pyramid scales 1 and 2 (exact half / quarter
+// sizes) from the staged bytes, so those scales need neither their own launch nor their own pass
+// over the frame; the staging then covers virtual rows ty0 - R - 1 .. and (border tiles) virtual
+// columns tx0 - RP - 1 .. with true REFLECT_101 instead of stopping one line past the image.
 // U8 = 1 fuses scale 0 of the pyramid (A1 at scale 1: convertTo + 3x3 [1/4,1/2,1/4] blur,
 // REFLECT_101; the resize is the identity) into the tile load, so the full-resolution
 // float image never exists in HBM.
 #define RC_POLY_BLOCK 512
+
 typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int R, int U8, int TH, int MFMA>
+// One output of pyramid scale 1 or 2 at pyr_scale 0.5 (exact 2:1 / 4:1 sizes) from 8-bit source
+// bytes staged in LDS: ub0 = byte (virtual row y0 - R, virtual column sx - R) of the
+// (2R+2) x (2R+2) footprint, REFLECT_101 already applied by the staging.  Same operation order
+// as rc_pyr_direct_body (row filter at the two sampled columns, column filter at the two sampled
+// rows, bilinear weights 1 - 0.5 and 0.5): same bits.
+template <int R>
+__device__ __forceinline__ float rc_pyr_from_lds(const unsigned char* ub0, int pitch, const float* kern) {
+    constexpr int KS = 2 * R + 1, NB = 2 * R + 2, NROW = 2 * R + 2;
+    float k[KS];
+#pragma unroll
+    for (int j = 0; j < KS; j++) k[j] = kern[j];
+    float rp0[NROW], rp1[NROW];
+#pragma unroll
+    for (int rr = 0; rr < NROW; rr++) {
+        float b[NB];
+#pragma unroll
+        for (int j = 0; j < NB; j++) b[j] = (float)ub0[rr * pitch + j];
+        rp0[rr] = rc_rowpass<R>(b, k);
+        rp1[rr] = rc_rowpass<R>(b + 1, k);
+    }
+    float b00 = k[R] * rp0[R], b01 = k[R] * rp1[R];
+    float b10 = k[R] * rp0[R + 1], b11 = k[R] * rp1[R + 1];
+#pragma unroll
+    for (int j = 1; j <= R; j++) {
+        b00 += k[R + j] * (rp0[R + j] + rp0[R - j]);
+        b01 += k[R + j] * (rp1[R + j] + rp1[R - j]);
+        b10 += k[R + j] * (rp0[R + 1 + j] + rp0[R + 1 - j]);
+        b11 += k[R + j] * (rp1[R + 1 + j] + rp1[R + 1 - j]);
+    }
+    const float a0 = 1.f - 0.5f, a1 = 0.5f;
+    float r0 = b00 * a0 + b01 * a1;
+    float r1 = b10 * a0 + b11 * a1;
+    return r0 * a0 + r1 * a1;
+}
+
+
+
+// One sampled column of a scale-2 output: the 9-tap row filter on the 10 virtual rows, then the column
+// filter at the two sampled rows (b0: rows R.., b1: rows R+1..).  rc_pyr_from_lds split in two so that
+// two lanes share an output; same operations on the same values.
+__device__ __forceinline__ void rc_pyr2_column(const unsigned char* u0, int pitch, const float* kern, float& b0, float& b1) {
+    constexpr int R = 4, KS = 9, NROW = 10;
+    float k[KS];
+#pragma unroll
+    for (int j = 0; j < KS; j++) k[j] = kern[j];
+    float rp[NROW];
+#pragma unroll
+    for (int rr = 0; rr < NROW; rr++) {
+        float b[KS];
+#pragma unroll
+        for (int j = 0; j < KS; j++) b[j] = (float)u0[rr * pitch + j];
+        rp[rr] = rc_rowpass<R>(b, k);
+    }
+    b0 = k[R] * rp[R];
+    b1 = k[R] * rp[R + 1];
+#pragma unroll
+    for (int j = 1; j <= R; j++) {
+        b0 += k[R + j] * (rp[R + j] + rp[R - j]);
+        b1 += k[R + j] * (rp[R + 1 + j] + rp[R + 1 - j]);
+    }
+}
+
+__device__ __forceinline__ float rc_lane_xor1(float v) {       // the value of lane ^ 1 (quad_perm [1,0,3,2])
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+}
+
+// The tile's outputs of pyramid scales 1 (32 x 16) and 2 (16 x 8): ub(row0, col0) = virtual image
+// (row0, col0).  With both scales, threads 0..255 take scale 2 (two lanes per output, one sampled column
+// each) and threads 256..511 two scale-1 outputs each, which balances the waves; scale 1 alone is one
+// output per thread.
+template <int R>
+__device__ __forceinline__ void rc_polyexp_pyr_phase(const RcPolyArgs& a, const unsigned char* ub, int pitch, int row0,
+                                                     int col0, int tx0, int ty0, int slot, int tid) {
+    const RcPyrFused& P1 = a.py[0];
+    auto scale1 = [&](int ox, int oy) {
+        const int dx = (tx0 >> 1) + ox, dy = (ty0 >> 1) + oy;
+        if (dx < P1.w && dy < P1.h) {
+            // source sample (2 dx + 0.5, 2 dy + 0.5): columns 2dx, 2dx+1, rows 2dy, 2dy+1, 3 taps
+            const unsigned char* u0 = ub + (ty0 + 2 * oy - 1 - row0) * pitch + (tx0 + 2 * ox - 1 - col0);
+            P1.dst[(size_t)slot * P1.dst_slot_stride + (size_t)dy * P1.w + dx] = rc_pyr_from_lds<1>(u0, pitch, P1.kern);
+        }
+    };
+    if (a.npyr >= 2) {
+        if (tid < 256) {
+            const RcPyrFused& P = a.py[1];
+            const int c = tid & 1, o = tid >> 1, ox = o & 15, oy = o >> 4;
+            const int dx = (tx0 >> 2) + ox, dy = (ty0 >> 2) + oy;
+            // source sample (4 dx + 1.5, 4 dy + 1.5): columns 4dx+1 (c = 0), 4dx+2 (c = 1), rows 4dy+1, 4dy+2, 9 taps
+            const unsigned char* u0 = ub + (ty0 + 4 * oy + 1 - 4 - row0) * pitch + (tx0 + 4 * ox + 1 - 4 + c - col0);
+            float b0, b1;
+            rc_pyr2_column(u0, pitch, P.kern, b0, b1);
+            const float o0 = rc_lane_xor1(b0), o1 = rc_lane_xor1(b1);
+            if (c == 0 && dx < P.w && dy < P.h) {
+                const float a0 = 1.f - 0.5f, a1 = 0.5f;
+                float r0 = b0 * a0 + o0 * a1;
+                float r1 = b1 * a0 + o1 * a1;
+                P.dst[(size_t)slot * P.dst_slot_stride + (size_t)dy * P.w + dx] = r0 * a0 + r1 * a1;
+            }
+        } else {
+            const int t = tid - 256;
+            scale1(t & 31, t >> 5);
+            scale1(t & 31, (t >> 5) + 8);
+        }
+    } else if (a.npyr >= 1) {
+        scale1(tid & 31, tid >> 5);
+    }
+}
+
+template <int R, int U8, int TH, int MFMA, int PYR = 0>
 __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int by, int z, float* smf) {
+    static_assert(!PYR || (U8 && TH == 32 && R >= 2), "fused pyramid: 8-bit scale 0, 64 x 32 tiles");
     constexpr int TW = 64, RP = (R + 3) & ~3;
     constexpr int INW = TW + 2 * RP, INH = TH + 2 * R;
     constexpr int NV = 4 + 2 * RP;
@@ -453,7 +567,7 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
         unsigned char* ub = (unsigned char*)hs;                    // [UBH][UBW]
         const uint8_t* src = a.src8 + (size_t)z * a.src8_frame_stride;
         dc = (float)src[(size_t)min(ty0 + TH / 2, h - 1) * a.src8_step + min(tx0 + TW / 2, w - 1)];
-        const int ylo = rc_clampi(ty0 - R, 0, h - 1) - 1;          // image row of staging row 0
+        const int ylo = PYR ? ty0 - R - 1 : rc_clampi(ty0 - R, 0, h - 1) - 1;   // image (PYR: virtual) row of staging row 0
         const int xs = tx0 - RP - 4;                               // fast path: image column of staging byte 0
         const bool fast = !a.no_fast_u8 && xs >= 0 && xs + UBW <= w &&
                           ((((size_t)a.src8) | a.src8_step | a.src8_frame_stride) & 3) == 0;
@@ -469,7 +583,7 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
             for (int q = 0; q < NLD; q++) {
                 int idx = tid + q * RC_POLY_BLOCK;
                 int i = idx / NDW, j = idx - i * NDW;
-                int sy = rc_reflect101(min(ylo + i, h), h);
+                int sy = rc_reflect101(PYR ? ylo + i : min(ylo + i, h), h);
                 v[q] = idx < UBH * NDW ? *(const unsigned int*)(src + (size_t)sy * a.src8_step + xs + 4 * j) : 0u;
             }
 #pragma unroll
@@ -478,6 +592,7 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
                 if (idx < UBH * NDW) ((unsigned int*)ub)[idx] = v[q];
             }
             __syncthreads();
+            if constexpr (PYR) rc_polyexp_pyr_phase<R>(a, ub, UBW, ylo, xs, tx0, ty0, slot, tid);
             const float mdc = -dc;
             for (int idx = tid; idx < INH * (INW / 4); idx += RC_POLY_BLOCK) {
                 int i = idx / (INW / 4), j4 = idx - i * (INW / 4);
@@ -505,7 +620,7 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
                 *(float4*)(tin + i * INW + 4 * j4) = o;
             }
         } else {
-            const int xlo = rc_clampi(tx0 - RP, 0, w - 1) - 1;
+            const int xlo = PYR ? tx0 - RP - 1 : rc_clampi(tx0 - RP, 0, w - 1) - 1;
             constexpr int UBWS = INW + 2;       // bytes used per staging row on this path
             constexpr int NLD = (UBH * UBWS + RC_POLY_BLOCK - 1) / RC_POLY_BLOCK;
             unsigned char v[NLD];
@@ -513,7 +628,7 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
             for (int q = 0; q < NLD; q++) {     // all loads in flight before the first LDS store
                 int idx = tid + q * RC_POLY_BLOCK;
                 int i = idx / UBWS, j = idx - i * UBWS;
-                int sy = rc_reflect101(min(ylo + i, h), h), sx = rc_reflect101(min(xlo + j, w), w);
+                int sy = rc_reflect101(PYR ? ylo + i : min(ylo + i, h), h), sx = rc_reflect101(PYR ? xlo + j : min(xlo + j, w), w);
                 v[q] = idx < UBH * UBWS ? src[(size_t)sy * a.src8_step + sx] : 0;
             }
 #pragma unroll
@@ -523,6 +638,7 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
                 if (idx < UBH * UBWS) ub[i * UBW + j] = v[q];
             }
             __syncthreads();
+            if constexpr (PYR) rc_polyexp_pyr_phase<R>(a, ub, UBW, ylo, xlo, tx0, ty0, slot, tid);
             for (int idx = tid; idx < INH * INW; idx += RC_POLY_BLOCK) {
                 int i = idx / INW, j = idx - i * INW;
                 int gy = rc_clampi(ty0 - R + i, 0, h - 1), gx = rc_clampi(tx0 - RP + j, 0, w - 1);
@@ -716,10 +832,10 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
     }
 }
 
-template <int R, int U8, int TH, int MFMA>
+template <int R, int U8, int TH, int MFMA, int PYR = 0>
 __global__ __launch_bounds__(RC_POLY_BLOCK) void k_polyexp(RcPolyArgs a) {
     extern __shared__ __align__(16) float rc_poly_smem[];
-    rc_polyexp_body<R, U8, TH, MFMA>(a, blockIdx.x, blockIdx.y, blockIdx.z, rc_poly_smem);
+    rc_polyexp_body<R, U8, TH, MFMA, PYR>(a, blockIdx.x, blockIdx.y, blockIdx.z, rc_poly_smem);
 }
 
 // The expansions of up to three scales of one frame (or a few) in ONE launch: scale 0 from the 8-bit
@@ -773,15 +889,15 @@ void rc_launch_polyexp_multi(const RcPolyArgs* a, int nlev, int frames, hipStrea
     else launch_polyexp_multi_t<7>(a, nlev, frames, s);
 }
 
-template <int R, int U8, int TH, int MFMA>
+template <int R, int U8, int TH, int MFMA, int PYR = 0>
 static void launch_polyexp_th(const RcPolyArgs& a, int frames, hipStream_t s) {
     constexpr int RP = (R + 3) & ~3;
     constexpr int INW = 64 + 2 * RP, INH = TH + 2 * R;
     constexpr size_t lds_hs = sizeof(float) * (3 * (size_t)INH * 64 + 3 * (2 * R + 1)), lds_ub = (size_t)(INH + 2) * (INW + 8);
     constexpr size_t lds = sizeof(float) * (size_t)INH * INW + (lds_hs > lds_ub ? lds_hs : lds_ub);
-    RC_ALLOW_LDS((k_polyexp<R, U8, TH, MFMA>), lds);
+    RC_ALLOW_LDS((k_polyexp<R, U8, TH, MFMA, PYR>), lds);
     dim3 grid((a.w + 63) / 64, (a.h + TH - 1) / TH, frames);
-    hipLaunchKernelGGL((k_polyexp<R, U8, TH, MFMA>), grid, dim3(RC_POLY_BLOCK), lds, s, a);
+    hipLaunchKernelGGL((k_polyexp<R, U8, TH, MFMA, PYR>), grid, dim3(RC_POLY_BLOCK), lds, s, a);
 }
 
 template <int R, int U8>
@@ -807,7 +923,21 @@ static void launch_polyexp_u(const RcPolyArgs& a, int frames, hipStream_t s) {
     else launch_polyexp_t<32, U8>(a, frames, s);
 }
 
+// Scale-0 expansion that also writes pyramid scales 1 (and 2): see PYR above.  The caller checked
+// rc_polyexp_pyr_ok and filled a.npyr / a.py.
+int rc_polyexp_pyr_ok(const RcPolyArgs& a) {
+    const int n = a.pk.n_eff;
+    return a.src8 && a.tile_h == 32 && a.valu_vertical && (n == 3 || n == 5 || n == 7);
+}
+
 void rc_launch_polyexp(const RcPolyArgs& a, int frames, hipStream_t s) {
+    if (a.npyr > 0) {
+        const int n = a.pk.n_eff;
+        if (n == 3) launch_polyexp_th<3, 1, 32, 0, 1>(a, frames, s);
+        else if (n == 5) launch_polyexp_th<5, 1, 32, 0, 1>(a, frames, s);
+        else launch_polyexp_th<7, 1, 32, 0, 1>(a, frames, s);
+        return;
+    }
     if (a.src8) launch_polyexp_u<1>(a, frames, s);
     else launch_polyexp_u<0>(a, frames, s);
 }

@@ -61,6 +61,14 @@ struct RcPyrArgs {
     int direct;               // diagnostic (RC_ABL_PYR_STAGED): the earlier per-pixel / LDS-staged kernels
 };
 
+// A pyramid scale written by the scale-0 expansion itself (k_polyexp<..., PYR = 1>)
+struct RcPyrFused {
+    float* dst;               // I_k slot base
+    size_t dst_slot_stride;   // floats per slot
+    int w, h;
+    const float* kern;        // device: 3 taps (scale 1) / 9 taps (scale 2)
+};
+
 struct RcPolyArgs {
     const float* I;           // I_k slot base (scales >= 1, and the stage entry point)
     size_t I_slot_stride;
@@ -75,6 +83,8 @@ struct RcPolyArgs {
     int no_fast_u8;           // diagnostic: byte-wise staging for every tile
     int valu_vertical;        // option "poly_mfma" = 0: vertical pass on the VALU instead of the matrix cores
     RcPolyK pk;
+    int npyr;                 // scale 0 only: pyramid scales 1..npyr come out of this launch too
+    RcPyrFused py[2];
 };
 
 // Option "ablate": earlier kernel forms and timing-only cuts kept for same-box A/B runs (0 in production).
@@ -141,6 +151,7 @@ struct RcIterArgs {
 
 void rc_launch_pyr(const RcPyrArgs& a, int frames, size_t lds, hipStream_t s);
 void rc_launch_polyexp(const RcPolyArgs& a, int frames, hipStream_t s);
+int rc_polyexp_pyr_ok(const RcPolyArgs& a);
 // merged launches for a frame or two (see pyr_polyexp_kernels.hip)
 int rc_pyr_pair_ok(const RcPyrArgs& a1, const RcPyrArgs& a2);
 void rc_launch_pyr_pair(const RcPyrArgs& a1, const RcPyrArgs& a2, int frames, hipStream_t s);

@@ -82,6 +82,7 @@ struct rc_ctx {
     int overlap = 0;           // option "overlap": clip path on two streams (measured: no gain, the grids fill the GPU)
     int poly_mfma = 0;          // option "poly_mfma": vertical pass of the expansion on the matrix cores (measured 25 % slower)
     int hist_blocks = 0;       // option "hist_blocks": cap on histogram blocks per launch (0 = default)
+    int fuse_pyr = 1;         // scale-0 expansion also writes pyramid scales 1 and 2 (exact 2:1 / 4:1 sizes)
     int ablate = 0;
     void* stamps = nullptr;
     int prof_on = 0;

@@ -253,6 +253,8 @@ extern "C" int rcflow_set_option(rc_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "poly_tile_h")) {
         if (value != 32 && value != 48) return RC_EINVAL;
         ctx->poly_tile_h = value;
+    } else if (!strcmp(name, "fuse_pyr")) {
+        ctx->fuse_pyr = value != 0;
     } else if (!strcmp(name, "ablate")) {
         ctx->ablate = value;
     } else if (!strcmp(name, "stamps")) {
@@ -553,7 +555,29 @@ static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t fr
     // smaller than the GPU and independent of one another, so scales 1 + 2 of the pyramid share one launch
     // and the expansions of scales 0..2 another (block-index dispatch; same tile code, same bits).
     const bool merge = ctx->merge_small && count <= 2;
-    int k_pyr = 1;
+    // Larger batches at pyr_scale 0.5 with exact half / quarter sizes: the scale-0 expansion writes
+    // pyramid scales 1 and 2 from the bytes it has staged anyway (option "fuse_pyr"; same bits)
+    int npyr = 0;
+    if (!merge && ctx->fuse_pyr && pl.nlev >= 2 && rc_polyexp_pyr_ok(qa[0])) {
+        auto exact = [&](int k, int f) { return pl.lv[k].w * f == pl.w && pl.lv[k].h * f == pl.h; };
+        if (exact(1, 2) && pl.lv[1].ksize == 3) {
+            npyr = 1;
+            if (pl.nlev >= 3 && exact(2, 4) && pl.lv[2].ksize == 9) npyr = 2;
+        }
+    }
+    if (npyr) {
+        RcPolyArgs& q = qa[0];
+        q.npyr = npyr;
+        double alg = 21. * npx(0), model = 29. * npx(0);
+        for (int k = 1; k <= npyr; k++) {
+            q.py[k - 1].dst = pa[k].dst; q.py[k - 1].dst_slot_stride = pa[k].dst_slot_stride;
+            q.py[k - 1].w = pa[k].w; q.py[k - 1].h = pa[k].h; q.py[k - 1].kern = pa[k].kern;
+            alg += 4. * npx(k); model += npx(0) + 4. * npx(k);
+        }
+        RcProfScope ps(ctx, s.cur, RC_K_POLY, 0, (double)count * alg, (double)count * model);
+        rc_launch_polyexp(q, count, s.cur);
+    }
+    int k_pyr = 1 + npyr;
     if (merge && pl.nlev >= 3 && rc_pyr_pair_ok(pa[1], pa[2])) {
         RcProfScope ps(ctx, s.cur, RC_K_PYR, 1, (double)count * (2. * npx(0) + 4. * (npx(1) + npx(2))));
         rc_launch_pyr_pair(pa[1], pa[2], count, s.cur);
@@ -572,6 +596,7 @@ static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t fr
         rc_launch_polyexp_multi(qa, nm, count, s.cur);
         k_poly = nm;
     }
+    if (npyr) k_poly = 1;
     for (int k = k_poly; k < pl.nlev; k++) {
         // SURVEY 8(d), scale 0: pyramid (N0 + 4 N0) + expansion (4 N0 + 20 N0) for the two stages fused there
         RcProfScope ps(ctx, s.cur, RC_K_POLY, k, (double)count * (k == 0 ? 21. : 24.) * npx(k),

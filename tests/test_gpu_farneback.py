@@ -316,6 +316,26 @@ def test_two_stream_overlap_option_same_bits(ctx):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("size,levels,n", [((640, 480), 2, 5), ((332, 252), 2, 4), ((328, 244), 1, 4), ((1024, 512), 4, 4),
+                                           ((64, 32), 2, 4), ((8, 8), 1, 4), ((72, 40), 2, 4), ((333, 251), 2, 4)])
+def test_fused_pyramid_same_bits(ctx, size, levels, n):
+    """Clips of more than two frames at pyr_scale 0.5 with exact half / quarter sizes: pyramid scales 1
+    and 2 come out of the scale-0 expansion launch (option fuse_pyr).  Same flow bits as with the
+    pyramid kernels (which test_pyr_level_bit_exact pins to the oracle); sizes that are not exact
+    multiples (333x251) take the pyramid kernels either way."""
+    w, h = size
+    clip = synth.surf_clip(w, h, n, seed=3)
+    p = dict(RC215, levels=levels)
+    try:
+        ctx.set_option("fuse_pyr", 0)
+        a = ctx.farneback_clip(clip, **p).cpu().numpy()
+        ctx.set_option("fuse_pyr", 1)
+        b = ctx.farneback_clip(clip, **p).cpu().numpy()
+    finally:
+        ctx.set_option("fuse_pyr", 1)
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
 def test_chunk_option_invariance(ctx):
     clip = torch.as_tensor(synth.surf_clip(256, 192, 6, seed=4)).cuda()
     a = ctx.farneback_clip(clip, **RC215).cpu().numpy()
