@@ -439,65 +439,23 @@ void rc_launch_pyr(const RcPyrArgs& a, int frames, size_t lds, hipStream_t s) {
 
 typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
 
-// One output of pyramid scale 1 or 2 at pyr_scale 0.5 (exact 2:1 / 4:1 sizes) from 8-bit source
-// bytes staged in LDS: ub0 = byte (virtual row y0 - R, virtual column sx - R) of the
-// (2R+2) x (2R+2) footprint, REFLECT_101 already applied by the staging.  Same operation order
-// as rc_pyr_direct_body (row filter at the two sampled columns, column filter at the two sampled
-// rows, bilinear weights 1 - 0.5 and 0.5): same bits.
-template <int R>
-__device__ __forceinline__ float rc_pyr_from_lds(const unsigned char* ub0, int pitch, const float* kern) {
-    constexpr int KS = 2 * R + 1, NB = 2 * R + 2, NROW = 2 * R + 2;
-    float k[KS];
+// NB consecutive staged bytes from any LDS byte address as floats: aligned dword reads, v_alignbyte,
+// v_cvt_f32_ubyteN (a byte-wise read costs the LDS pipe as much as a dword).  Reads up to 3 bytes past
+// the last one asked for: the staging area is followed by the rest of the block's LDS.
+template <int NB>
+__device__ __forceinline__ void rc_lds_bytes_f32(const unsigned char* p, float* b) {
+    constexpr int NV = (NB + 3) / 4, ND = NV + 1;
+    const unsigned sh = (unsigned)(size_t)p & 3u;
+    const unsigned int* q = (const unsigned int*)(p - sh);
+    unsigned int d[ND];
 #pragma unroll
-    for (int j = 0; j < KS; j++) k[j] = kern[j];
-    float rp0[NROW], rp1[NROW];
+    for (int i = 0; i < ND; i++) d[i] = q[i];
 #pragma unroll
-    for (int rr = 0; rr < NROW; rr++) {
-        float b[NB];
+    for (int i = 0; i < NV; i++) {
+        const unsigned int v = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
 #pragma unroll
-        for (int j = 0; j < NB; j++) b[j] = (float)ub0[rr * pitch + j];
-        rp0[rr] = rc_rowpass<R>(b, k);
-        rp1[rr] = rc_rowpass<R>(b + 1, k);
-    }
-    float b00 = k[R] * rp0[R], b01 = k[R] * rp1[R];
-    float b10 = k[R] * rp0[R + 1], b11 = k[R] * rp1[R + 1];
-#pragma unroll
-    for (int j = 1; j <= R; j++) {
-        b00 += k[R + j] * (rp0[R + j] + rp0[R - j]);
-        b01 += k[R + j] * (rp1[R + j] + rp1[R - j]);
-        b10 += k[R + j] * (rp0[R + 1 + j] + rp0[R + 1 - j]);
-        b11 += k[R + j] * (rp1[R + 1 + j] + rp1[R + 1 - j]);
-    }
-    const float a0 = 1.f - 0.5f, a1 = 0.5f;
-    float r0 = b00 * a0 + b01 * a1;
-    float r1 = b10 * a0 + b11 * a1;
-    return r0 * a0 + r1 * a1;
-}
-
-
-
-// One sampled column of a scale-2 output: the 9-tap row filter on the 10 virtual rows, then the column
-// filter at the two sampled rows (b0: rows R.., b1: rows R+1..).  rc_pyr_from_lds split in two so that
-// two lanes share an output; same operations on the same values.
-__device__ __forceinline__ void rc_pyr2_column(const unsigned char* u0, int pitch, const float* kern, float& b0, float& b1) {
-    constexpr int R = 4, KS = 9, NROW = 10;
-    float k[KS];
-#pragma unroll
-    for (int j = 0; j < KS; j++) k[j] = kern[j];
-    float rp[NROW];
-#pragma unroll
-    for (int rr = 0; rr < NROW; rr++) {
-        float b[KS];
-#pragma unroll
-        for (int j = 0; j < KS; j++) b[j] = (float)u0[rr * pitch + j];
-        rp[rr] = rc_rowpass<R>(b, k);
-    }
-    b0 = k[R] * rp[R];
-    b1 = k[R] * rp[R + 1];
-#pragma unroll
-    for (int j = 1; j <= R; j++) {
-        b0 += k[R + j] * (rp[R + j] + rp[R - j]);
-        b1 += k[R + j] * (rp[R + 1 + j] + rp[R + 1 - j]);
+        for (int t = 0; t < 4; t++)
+            if (4 * i + t < NB) b[4 * i + t] = (float)((v >> (8 * t)) & 255u);
     }
 }
 
@@ -505,45 +463,79 @@ __device__ __forceinline__ float rc_lane_xor1(float v) {       // the value of l
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
 }
 
-// The tile's outputs of pyramid scales 1 (32 x 16) and 2 (16 x 8): ub(row0, col0) = virtual image
-// (row0, col0).  With both scales, threads 0..255 take scale 2 (two lanes per output, one sampled column
-// each) and threads 256..511 two scale-1 outputs each, which balances the waves; scale 1 alone is one
-// output per thread.
+// The tile's outputs of pyramid scales 1 (32 x 16) and 2 (16 x 8) at exact 2:1 / 4:1 sizes, from the
+// staged bytes: ub(row0, col0) = virtual image (row0, col0), REFLECT_101 applied by the staging.
+// A thread takes two vertically adjacent outputs, which share row-filter results (6 instead of 8 rows
+// at scale 1, 14 instead of 20 at scale 2); at scale 2 two lanes share the pair, one sampled column
+// each.  Operation order per output is rc_pyr_direct_body's (row filter at the two sampled columns,
+// column filter at the two sampled rows, bilinear weights 1 - 0.5 and 0.5): same bits.
 template <int R>
 __device__ __forceinline__ void rc_polyexp_pyr_phase(const RcPolyArgs& a, const unsigned char* ub, int pitch, int row0,
                                                      int col0, int tx0, int ty0, int slot, int tid) {
-    const RcPyrFused& P1 = a.py[0];
-    auto scale1 = [&](int ox, int oy) {
-        const int dx = (tx0 >> 1) + ox, dy = (ty0 >> 1) + oy;
-        if (dx < P1.w && dy < P1.h) {
-            // source sample (2 dx + 0.5, 2 dy + 0.5): columns 2dx, 2dx+1, rows 2dy, 2dy+1, 3 taps
-            const unsigned char* u0 = ub + (ty0 + 2 * oy - 1 - row0) * pitch + (tx0 + 2 * ox - 1 - col0);
-            P1.dst[(size_t)slot * P1.dst_slot_stride + (size_t)dy * P1.w + dx] = rc_pyr_from_lds<1>(u0, pitch, P1.kern);
+    const float a0 = 1.f - 0.5f, a1 = 0.5f;
+    const int t1 = a.npyr >= 2 ? tid - 128 : tid;            // scale 1: 256 threads, one output pair each
+    if (a.npyr >= 2 && tid < 128) {
+        const RcPyrFused& P = a.py[1];
+        const int c = tid & 1, o = tid >> 1, ox = o & 15, oyp = o >> 4;
+        const int dx = (tx0 >> 2) + ox, dy = (ty0 >> 2) + 2 * oyp;
+        // source samples (4 dx + 1.5, 4 dy + 1.5): columns 4dx+1 (c = 0) / 4dx+2 (c = 1), rows 4dy+1, 4dy+2; 9 taps
+        const unsigned char* u0 = ub + (ty0 + 8 * oyp + 1 - 4 - row0) * pitch + (tx0 + 4 * ox + 1 - 4 + c - col0);
+        float k[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) k[j] = P.kern[j];
+        float rp[14];
+#pragma unroll
+        for (int rr = 0; rr < 14; rr++) {
+            float b[9];
+            rc_lds_bytes_f32<9>(u0 + rr * pitch, b);
+            rp[rr] = rc_rowpass<4>(b, k);
         }
-    };
-    if (a.npyr >= 2) {
-        if (tid < 256) {
-            const RcPyrFused& P = a.py[1];
-            const int c = tid & 1, o = tid >> 1, ox = o & 15, oy = o >> 4;
-            const int dx = (tx0 >> 2) + ox, dy = (ty0 >> 2) + oy;
-            // source sample (4 dx + 1.5, 4 dy + 1.5): columns 4dx+1 (c = 0), 4dx+2 (c = 1), rows 4dy+1, 4dy+2, 9 taps
-            const unsigned char* u0 = ub + (ty0 + 4 * oy + 1 - 4 - row0) * pitch + (tx0 + 4 * ox + 1 - 4 + c - col0);
-            float b0, b1;
-            rc_pyr2_column(u0, pitch, P.kern, b0, b1);
-            const float o0 = rc_lane_xor1(b0), o1 = rc_lane_xor1(b1);
-            if (c == 0 && dx < P.w && dy < P.h) {
-                const float a0 = 1.f - 0.5f, a1 = 0.5f;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            float b0 = k[4] * rp[4 * e + 4], b1 = k[4] * rp[4 * e + 5];
+#pragma unroll
+            for (int j = 1; j <= 4; j++) {
+                b0 += k[4 + j] * (rp[4 * e + 4 + j] + rp[4 * e + 4 - j]);
+                b1 += k[4 + j] * (rp[4 * e + 5 + j] + rp[4 * e + 5 - j]);
+            }
+            const float o0 = rc_lane_xor1(b0), o1 = rc_lane_xor1(b1);      // the other sampled column
+            if (c == 0 && dx < P.w && dy + e < P.h) {
                 float r0 = b0 * a0 + o0 * a1;
                 float r1 = b1 * a0 + o1 * a1;
-                P.dst[(size_t)slot * P.dst_slot_stride + (size_t)dy * P.w + dx] = r0 * a0 + r1 * a1;
+                P.dst[(size_t)slot * P.dst_slot_stride + (size_t)(dy + e) * P.w + dx] = r0 * a0 + r1 * a1;
             }
-        } else {
-            const int t = tid - 256;
-            scale1(t & 31, t >> 5);
-            scale1(t & 31, (t >> 5) + 8);
         }
-    } else if (a.npyr >= 1) {
-        scale1(tid & 31, tid >> 5);
+    } else if (a.npyr >= 1 && t1 < 256) {
+        const RcPyrFused& P = a.py[0];
+        const int ox = t1 & 31, oyp = t1 >> 5;
+        const int dx = (tx0 >> 1) + ox, dy = (ty0 >> 1) + 2 * oyp;
+        // source samples (2 dx + 0.5, 2 dy + 0.5): columns 2dx, 2dx+1, rows 2dy, 2dy+1; 3 taps
+        const unsigned char* u0 = ub + (ty0 + 4 * oyp - 1 - row0) * pitch + (tx0 + 2 * ox - 1 - col0);
+        float k[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) k[j] = P.kern[j];
+        float rp0[6], rp1[6];
+#pragma unroll
+        for (int rr = 0; rr < 6; rr++) {
+            float b[4];
+            rc_lds_bytes_f32<4>(u0 + rr * pitch, b);
+            rp0[rr] = rc_rowpass<1>(b, k);
+            rp1[rr] = rc_rowpass<1>(b + 1, k);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            float b00 = k[1] * rp0[2 * e + 1], b01 = k[1] * rp1[2 * e + 1];
+            float b10 = k[1] * rp0[2 * e + 2], b11 = k[1] * rp1[2 * e + 2];
+            b00 += k[2] * (rp0[2 * e + 2] + rp0[2 * e]);
+            b01 += k[2] * (rp1[2 * e + 2] + rp1[2 * e]);
+            b10 += k[2] * (rp0[2 * e + 3] + rp0[2 * e + 1]);
+            b11 += k[2] * (rp1[2 * e + 3] + rp1[2 * e + 1]);
+            if (dx < P.w && dy + e < P.h) {
+                float r0 = b00 * a0 + b01 * a1;
+                float r1 = b10 * a0 + b11 * a1;
+                P.dst[(size_t)slot * P.dst_slot_stride + (size_t)(dy + e) * P.w + dx] = r0 * a0 + r1 * a1;
+            }
+        }
     }
 }
 
