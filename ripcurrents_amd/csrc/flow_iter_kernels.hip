@@ -1223,10 +1223,22 @@ __global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
         const int sx1 = min(sx + 1, a.fin_w - 1);
         const int rb = (gys[0] - 1) >> 1;
         float2 t0[NR], t1[NR];
+        // no column of the block clamped either: texels sx and sx + 1 are one 16-byte load (8-byte aligned)
+        typedef float rc_f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+        const bool cols_plain = tx0 - 2 >= 1 && tx0 - 2 + MW <= w && ((tx0 - 2 + MW - 2) >> 1) + 1 <= a.fin_w - 1;
+        if (cols_plain) {
 #pragma unroll
-        for (int j = 0; j < NR; j++) {
-            const float2* S = fin + (size_t)rc_clampi(rb + j, 0, a.fin_h - 1) * a.fin_w;
-            t0[j] = S[sx]; t1[j] = S[sx1];
+            for (int j = 0; j < NR; j++) {
+                const float2* S = fin + (size_t)rc_clampi(rb + j, 0, a.fin_h - 1) * a.fin_w;
+                const rc_f4a8 v = *(const rc_f4a8*)(S + sx);
+                t0[j] = make_float2(v.x, v.y); t1[j] = make_float2(v.z, v.w);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const float2* S = fin + (size_t)rc_clampi(rb + j, 0, a.fin_h - 1) * a.fin_w;
+                t0[j] = S[sx]; t1[j] = S[sx1];
+            }
         }
         const float a0 = 1.f - ax, a1 = ax;
         float hx[NR], hy[NR];
