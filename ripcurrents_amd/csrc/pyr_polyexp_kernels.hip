@@ -817,8 +817,11 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
                 ra.z = (float)((double)b1[o] * a.pk.ig03 + (double)b5[o] * a.pk.ig33 + dck);
                 ra.w = (float)((double)b1[o] * a.pk.ig03 + (double)b4[o] * a.pk.ig33 + dck);
                 size_t p = (size_t)gy * w + gx;
-                RA[p] = ra;
-                RB[p] = b6[o] * ig55f;
+                // streaming stores: R is written once here and read by the flow kernels much later (the
+                // batch's R does not fit the caches), and this kernel is bound by its writes (-1.4 % per pair)
+                __builtin_nontemporal_store(ra.x, &RA[p].x); __builtin_nontemporal_store(ra.y, &RA[p].y);
+                __builtin_nontemporal_store(ra.z, &RA[p].z); __builtin_nontemporal_store(ra.w, &RA[p].w);
+                __builtin_nontemporal_store(b6[o] * ig55f, &RB[p]);
             }
         }
     }
