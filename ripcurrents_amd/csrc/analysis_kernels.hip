@@ -123,7 +123,9 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist(const float* flow0, siz
             if (it0 + u < rounds && y < h) {
                 const float2* r = rc_row2(flow, step, y) + x;
                 if (x + 1 < w && (((size_t)r) & 15) == 0) {
-                    v[u] = *(const float4*)r;
+                    typedef float rc_f4 __attribute__((ext_vector_type(4)));
+                    const rc_f4 t = __builtin_nontemporal_load((const rc_f4*)r);
+                    v[u] = make_float4(t.x, t.y, t.z, t.w);
                     nv[u] = 2;
                 } else {
                     float2 a0 = r[0];
