@@ -60,6 +60,18 @@ __global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ s, floa
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) d[i] = s[i];
 }
 
+typedef float rc_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_write_nt(rc_f4* __restrict__ p, size_t n4) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    const rc_f4 v = {1.f, 2.f, 3.f, 4.f};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) __builtin_nontemporal_store(v, p + i);
+}
+__global__ __launch_bounds__(256) void k_copy_nt(const rc_f4* __restrict__ s, rc_f4* __restrict__ d, size_t n4) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(s + i), d + i);
+}
+
 template <class F> static double timeit(F f, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int i = 0; i < 3; i++) f();
@@ -85,6 +97,9 @@ int main() {
             double td = timeit([&] { hipLaunchKernelGGL(k_read_dma, dim3(blocks), dim3(256), 0, 0, src, n4, out); }, 10);
             double tw = timeit([&] { hipLaunchKernelGGL(k_write, dim3(blocks), dim3(256), 0, 0, dst, n4); }, 10);
             double tcp = timeit([&] { hipLaunchKernelGGL(k_copy, dim3(blocks), dim3(256), 0, 0, src, dst, n4); }, 10);
+            double twn = timeit([&] { hipLaunchKernelGGL(k_write_nt, dim3(blocks), dim3(256), 0, 0, (rc_f4*)dst, n4); }, 10);
+            double tcn = timeit([&] { hipLaunchKernelGGL(k_copy_nt, dim3(blocks), dim3(256), 0, 0, (const rc_f4*)src, (rc_f4*)dst, n4); }, 10);
+            printf("blocks %6d  nontemporal: write %.2f  copy(r+w) %.2f TB/s\n", blocks, bytes / twn * 1e-12, 2.0 * bytes / tcn * 1e-12);
             printf("blocks %6d  read u1 %.2f  u4 %.2f  u8 %.2f  chunk u8 %.2f  lds-dma %.2f | write %.2f | copy(r+w) %.2f  TB/s\n", blocks,
                    bytes / t1 * 1e-12, bytes / t4 * 1e-12, bytes / t8 * 1e-12, bytes / tc * 1e-12, bytes / td * 1e-12,
                    bytes / tw * 1e-12, 2.0 * bytes / tcp * 1e-12);
