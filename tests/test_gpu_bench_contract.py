@@ -35,3 +35,24 @@ def test_bench_prints_one_contract_line():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+
+
+def test_bench_two_ranks_rehearsal():
+    """The N>1 path of bench.py end to end on the one GPU of the test box: two ranks launched the way the
+    driver launches them (torch.distributed.run), both on cuda:0 with gloo as the transport
+    (RC_REHEARSE_GLOO=1; RCCL refuses two ranks on one device).  Segments per rank, the asynchronous
+    histogram all-reduce consumed one step later, max-over-ranks timing, one JSON line from rank 0."""
+    env = dict(os.environ, RC_REHEARSE_GLOO="1")
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--pairs", "4", "--no-roof"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and j["config"]["segments"] == 2
+    assert "all_reduce int32[1887]" in j["config"]["collective"]
+    assert abs(j["value"] - 2 * 4 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 0.01
+    assert "cpu_baseline" not in j          # rank 0 at N = 1 only
