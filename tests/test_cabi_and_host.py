@@ -111,3 +111,15 @@ def test_headers_are_plain_c(tmp_path):
                         "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_every_option_is_documented_in_the_header():
+    """rcflow_set_option's names (csrc/rcflow_api.hip) all appear in include/rcflow.h's option list."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "ripcurrents_amd", "csrc", "rcflow_api.hip")).read()
+    hdr = open(os.path.join(root, "include", "rcflow.h")).read()
+    names = set(re.findall(r'strcmp\(name, "([a-z_0-9]+)"\)', src))
+    assert len(names) >= 10
+    missing = [n for n in sorted(names) if '"%s"' % n not in hdr]
+    assert not missing, missing
