@@ -73,6 +73,54 @@ def test_histogram_edge_cases(ctx, orc):
     assert np.array_equal(st.hist2d, ost.hist2d) and st.hist[6] == w * h
 
 
+def test_histogram_key_on_bin_edges(ctx, orc):
+    """Adversarial field for the bin / direction floors: magnitudes at k/20 and directions at multiples of
+    10 degrees to within a few ulps, axis-aligned and diagonal vectors, zeros, denormals, huge values, Inf
+    and NaN (a NaN magnitude is not counted: it converts to INT_MIN on the reference's x86).  Counts must
+    equal the oracle's exactly."""
+    w, h = 2048, 1024
+    n = w * h
+    rng = np.random.RandomState(11)
+    f = np.empty((n, 2), np.float32)
+    q = n // 8
+    # 1: magnitudes on the bin edges, random direction
+    k = rng.randint(1, 51, q).astype(np.float64) / 20.0
+    th = rng.rand(q) * 2 * np.pi
+    f[:q, 0] = k * np.cos(th); f[:q, 1] = k * np.sin(th)
+    # 2: directions on the 10-degree edges, random magnitude, then nudged by a few ulps
+    m = rng.randint(0, 37, q) * (np.pi / 18)
+    r = rng.rand(q) * 2.6
+    f[q:2 * q, 0] = r * np.cos(m); f[q:2 * q, 1] = r * np.sin(m)
+    nudged = f[q:2 * q].view(np.int32) + rng.randint(-3, 4, (q, 2)).astype(np.int32)
+    f[q:2 * q] = nudged.view(np.float32)
+    # 3: both at once
+    k = rng.randint(1, 51, q).astype(np.float64) / 20.0
+    m = rng.randint(0, 37, q) * (np.pi / 18)
+    f[2 * q:3 * q, 0] = k * np.cos(m); f[2 * q:3 * q, 1] = k * np.sin(m)
+    # 4: axis-aligned / diagonal with magnitudes on a fine lattice
+    v = (rng.randint(-60, 61, (q, 2)) * 0.05).astype(np.float32)
+    v[rng.rand(q) < 0.3, 0] = 0
+    v[rng.rand(q) < 0.3, 1] = 0
+    f[3 * q:4 * q] = v
+    # 5: ordinary smooth and random vectors
+    f[4 * q:6 * q] = rng.randn(2 * q, 2) * 0.8
+    f[6 * q:7 * q] = (rng.rand(q, 2) - 0.5) * 5.2
+    # 6: extremes
+    ex = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-39, 1e-30, 1e-20, 1e-10, 2.45, 2.5, 2.55, 1e10, 1e20, 3e38, np.inf, -np.inf,
+                   np.nan, 0.05, 0.1, 1.0], np.float32)
+    f[7 * q:, 0] = ex[rng.randint(0, len(ex), n - 7 * q)]
+    f[7 * q:, 1] = ex[rng.randint(0, len(ex), n - 7 * q)]
+    f = f[rng.permutation(n)].reshape(h, w, 2)
+    st, ost = HistState(), orc.HistState()
+    ctx.analysis_reset(w, h)
+    with np.errstate(all="ignore"):
+        ctx.create_histogram(f, st)
+        orc.create_histogram(orc.flow_to_polar(f), ost)
+    assert st.histsum == ost.histsum.value and st.histsum > n // 2
+    assert np.array_equal(st.hist2d, ost.hist2d)
+    assert st.UPPER == ost.UPPER and np.array_equal(st.UPPER2d, ost.UPPER2d)
+
+
 def test_histogram_random_directions(ctx, orc):
     """Uniformly random vectors: every wave holds ~64 distinct bins (the slow path of the
     ballot grouping)."""
