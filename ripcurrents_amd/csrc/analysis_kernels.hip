@@ -48,7 +48,7 @@ __device__ __forceinline__ float rc_fast_atan2_deg(float y, float x) {
 // int angle = (a * HIST_DIRECTIONS) / 360 (ripcurrents_module.cpp:100); 36 (a == 360.0f, an
 // out-of-bounds index in the reference) folds to direction 0.
 __device__ __forceinline__ int rc_dir_index(float angle) {
-    int d = (int)((angle * RC_HIST_DIRECTIONS) / 360);
+    int d = rc_cvt_i32_x86((angle * RC_HIST_DIRECTIONS) / 360);
     if (d >= RC_HIST_DIRECTIONS || d < 0) d = 0;
     return d;
 }
@@ -86,9 +86,8 @@ __device__ __forceinline__ void rc_hist_add(int* lh, int key) {
 
 __device__ __forceinline__ int rc_hist_key(float2 f) {
     float mag = sqrtf(f.x * f.x + f.y * f.y);
-    int bin = (int)(mag * RC_HIST_RESOLUTION);
-    // a NaN magnitude converts to INT_MIN on the reference's x86 (not counted); v_cvt_i32_f32 gives 0
-    if (!(bin < RC_HIST_BINS && bin >= 0) || mag != mag) return -1;
+    int bin = rc_cvt_i32_x86(mag * RC_HIST_RESOLUTION);      // NaN: INT_MIN, not counted
+    if (!(bin < RC_HIST_BINS && bin >= 0)) return -1;
     return rc_dir_index(rc_fast_atan2_deg(f.y, f.x)) * RC_HIST_BINS + bin;
 }
 
@@ -317,7 +316,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_classify_accumulate(ClassifyArgs a
 // Bilinear sampler shared by every streamline variant (ripcurrents_module.cpp:494-508).
 __device__ __forceinline__ bool rc_sample_flow(const float* flow, size_t step, int w, int h, float x, float y,
                                                float& dx, float& dy) {
-    int xind = (int)floorf(x), yind = (int)floorf(y);
+    int xind = rc_cvt_i32_x86(floorf(x)), yind = rc_cvt_i32_x86(floorf(y));
     float xrem = x - xind, yrem = y - yind;
     if (xind < 1 || yind < 1 || xind + 2 > w || yind + 2 > h) return false;
     const float2* r0 = rc_row2(flow, step, yind) + xind;
@@ -1081,7 +1080,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_positions(const float2* __restrict
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const float2 p = pt[(size_t)y * w + x];
-    const int xind = (int)roundf(floorf(p.x + x)), yind = (int)roundf(floorf(p.y + y));
+    const int xind = rc_cvt_i32_x86(roundf(floorf(p.x + x))), yind = rc_cvt_i32_x86(roundf(floorf(p.y + y)));
     if (xind < 1 || yind < 1 || xind + 2 > w || yind + 2 > h) return;
     float* d = (float*)((char*)density + (size_t)yind * density_step) + 3 * xind;
     d[0] = 1.f; d[1] = 1.f; d[2] = 1.f;        // every writer stores the same value: order is irrelevant
@@ -1100,7 +1099,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_hsv_to_bgr(const float* __restrict
         hh *= 6.f / 360.f;
         if (hh < 0) do hh += 6; while (hh < 0);
         else if (hh >= 6) do hh -= 6; while (hh >= 6);
-        int sector = (int)floorf(hh);
+        int sector = rc_cvt_i32_x86(floorf(hh));
         hh -= sector;
         if ((unsigned)sector >= 6u) { sector = 0; hh = 0.f; }
         const float t0 = vv, t1 = vv * (1.f - ss), t2 = vv * (1.f - ss * hh), t3 = vv * (1.f - ss * (1.f - hh));

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(RC_LK_THREADS) void k_lk_track(RcLkArgs a) {
         }
         nxt = make_float2(nx, ny);
         px -= halfx; py -= halfy;
-        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        const int ipx = rc_cvt_i32_x86(floorf(px)), ipy = rc_cvt_i32_x86(floorf(py));
         if (ipx < -win_w || ipx >= L.w || ipy < -win_h || ipy >= L.h) {
             if (level == 0) { ok = false; errv = 0.f; }
             continue;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(RC_LK_THREADS) void k_lk_track(RcLkArgs a) {
         nx -= halfx; ny -= halfy;
         float pdx = 0.f, pdy = 0.f;
         for (int j = 0; j < a.max_count; j++) {
-            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            const int inx = rc_cvt_i32_x86(floorf(nx)), iny = rc_cvt_i32_x86(floorf(ny));
             if (inx < -win_w || inx >= L.w || iny < -win_h || iny >= L.h) {
                 if (level == 0) ok = false;
                 break;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(RC_LK_THREADS) void k_lk_track(RcLkArgs a) {
         if (ok && level == 0 && !get_min_eig) {
             // L1 residual of the final position (the err output without GET_MIN_EIGENVALS)
             const float fx = nxt.x - halfx, fy = nxt.y - halfy;
-            const int inx = (int)floorf(fx), iny = (int)floorf(fy);
+            const int inx = rc_cvt_i32_x86(floorf(fx)), iny = rc_cvt_i32_x86(floorf(fy));
             if (inx < -win_w || inx >= L.w || iny < -win_h || iny >= L.h) {
                 ok = false;
             } else {

@@ -13,6 +13,13 @@
 // Built with -ffp-contract=off: a*b+c rounds twice unless written as fmaf().
 #define RC_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 
+// `(int)float` as the reference's x86 build compiles it (cvttss2si): NaN and values outside int range give
+// INT_MIN ("integer indefinite"), where v_cvt_i32_f32 gives 0 and saturates.  Bounds checks written
+// for the x86 result (x < 1 || x + 2 > w) then reject such positions instead of letting them through.
+__device__ __forceinline__ int rc_cvt_i32_x86(float v) {
+    return (v >= -2147483648.f && v < 2147483648.f) ? (int)v : (int)0x80000000;
+}
+
 // Geometry and constants of one pyramid scale.
 struct RcLevel {
     int w, h;            // level size (cvRound(W*scale))

@@ -121,6 +121,68 @@ def test_histogram_key_on_bin_edges(ctx, orc):
     assert st.UPPER == ost.UPPER and np.array_equal(st.UPPER2d, ost.UPPER2d)
 
 
+def _adversarial_flow(w, h, seed):
+    """Ordinary vectors mixed with zeros, denormals, magnitudes exactly on the 0.2 / 0.5 class thresholds,
+    huge values, Inf and NaN."""
+    n = w * h
+    rng = np.random.RandomState(seed)
+    ex = np.array([0.0, -0.0, 1e-45, 1e-39, 1e-20, 0.2, 0.5, 0.05, 1.0, 1.7, 2.5, 1e10, 3e38, np.inf, -np.inf, np.nan],
+                  np.float32)
+    f = (rng.randn(n, 2) * 0.8).astype(np.float32)
+    for c in (0, 1):
+        idx = rng.rand(n) < 0.3
+        f[idx, c] = ex[rng.randint(0, len(ex), idx.sum())]
+    k = rng.rand(n) < 0.1
+    th = rng.rand(k.sum()) * 2 * np.pi
+    r = np.where(rng.rand(k.sum()) < 0.5, 0.2, 0.5)
+    f[k, 0] = (r * np.cos(th)).astype(np.float32)
+    f[k, 1] = (r * np.sin(th)).astype(np.float32)
+    return f.reshape(h, w, 2)
+
+
+def test_analysis_on_adversarial_flow(ctx, orc):
+    """Every per-pixel analysis kernel on a field with huge, infinite and NaN vectors: same results as the
+    oracle, whose `(int)float` conversions are the reference's x86 ones (NaN / out of range -> INT_MIN).  A
+    particle carried to 3e38 must be rejected by the sampler's bounds check like there, not wrap it."""
+    w, h = 512, 256
+    f = _adversarial_flow(w, h, 5)
+    eq = lambda a, b: np.array_equal(a, b, equal_nan=True)
+    with np.errstate(all="ignore"):
+        ctx.analysis_reset(w, h)
+        st, ost = HistState(), orc.HistState()
+        ctx.create_histogram(f, st)
+        polar = orc.flow_to_polar(f)
+        orc.create_histogram(polar, ost)
+        assert eq(st.hist2d, ost.hist2d) and st.UPPER == ost.UPPER and eq(st.UPPER2d, ost.UPPER2d)
+        acc = np.zeros((h, w, 3), np.float32)
+        for fc in (1, 31, 32, 40):
+            outs = ctx.create_flow_accumulate(f, fc)
+            wc = np.zeros((h, w, 3), np.float32)
+            acc2 = np.zeros((h, w, 3), np.float32)
+            p2 = polar.copy()
+            orc.create_flow(p2, wc, acc2, ost.UPPER, 0.5, 0.2, ost.UPPER2d)
+            out = np.zeros((h, w, 3), np.float32)
+            mask = np.zeros((h, w), np.uint8)
+            orc.create_accumulationbuffer(acc, acc2, out, mask, fc)
+            assert eq(outs["waterclass"].cpu().numpy(), wc) and eq(outs["polar"].cpu().numpy(), p2)
+            assert eq(outs["out"].cpu().numpy(), out) and eq(outs["outmask"].cpu().numpy(), mask)
+            assert eq(ctx.accumulator(w, h), acc[..., 0])
+        ctx.analysis_reset(w, h)
+        pt = np.zeros((h, w, 2), np.float32)
+        dist = np.zeros((h, w), np.float32)
+        for _ in range(3):
+            ctx.streamline_field(f, 2.0, 2, UPPER=1.7)
+            orc.streamline_field(pt, dist, f, 2.0, 2, 1.7)
+        gpt, gdist = ctx.streamline_field_state(w, h)
+        assert eq(gpt, pt) and eq(gdist, dist)
+        pts = (np.random.RandomState(6).rand(300, 2) * [w, h]).astype(np.float32)
+        for variant in range(5):          # variant 2 has no cutoff: positions run off to huge values
+            g, _ = ctx.streamline(pts.copy(), f, 0.1, 20, 1.7, variant=variant)
+            o = pts.copy()
+            orc.streamline_points(o, f, 0.1, 20, 1.7, variant=variant)
+            assert eq(g.cpu().numpy() if hasattr(g, "cpu") else np.asarray(g), o)
+
+
 def test_histogram_random_directions(ctx, orc):
     """Uniformly random vectors: every wave holds ~64 distinct bins (the slow path of the
     ballot grouping)."""

@@ -48,6 +48,28 @@ def test_pyrlk_matches_oracle(ctx, orc, clip, size, win, eps, flags):
         assert np.abs(er[good] - ref_er[good]).max() <= 16.0 / (32 * win[0] * win[1])
 
 
+def test_pyrlk_unusable_points(ctx, orc):
+    """NaN, infinite and huge point coordinates: status 0 like the oracle (x86 conversions give INT_MIN,
+    which fails the window bounds check), never an out-of-bounds read; the other points are unaffected."""
+    w, h = 320, 240
+    fr = synth.surf_clip(w, h, 2)
+    pts = _points(w, h, 40, 3)
+    pts[5] = (np.nan, 50.0)
+    pts[6] = (60.0, np.nan)
+    pts[7] = (np.inf, 10.0)
+    pts[8] = (-np.inf, -np.inf)
+    pts[9] = (3e38, 3e38)
+    pts[10] = (-3e38, 100.0)
+    pts[11] = (2147483648.0, 5.0)
+    with np.errstate(all="ignore"):
+        ref_q, ref_st, _ = orc.pyrlk(fr[0], fr[1], pts, win=(21, 21), max_level=3)
+        q, st, _ = ctx.calcOpticalFlowPyrLK(fr[0], fr[1], pts, win=(21, 21), max_level=3)
+    q, st = q.cpu().numpy(), st.cpu().numpy()
+    assert np.array_equal(st, ref_st) and not st[5:12].any() and st[12:].all()
+    good = ref_st == 1
+    assert np.abs(q[good] - ref_q[good]).max() < 0.15
+
+
 def test_pyrlk_initial_flow_and_strided_input(ctx, orc):
     import torch
     w, h = 320, 240
