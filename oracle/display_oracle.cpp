@@ -121,8 +121,12 @@ extern "C" void orc_hsv_to_bgr_f32(const float* hsv, size_t hsv_step, int w, int
             else {
                 float tab[4];
                 hh *= hscale;
-                if (hh < 0) do hh += 6; while (hh < 0);
-                else if (hh >= 6) do hh -= 6; while (hh >= 6);
+                // color_hsv.cpp wraps the hue with `do h -= 6; while (h >= 6)`, which never ends for an infinite or
+                // huge hue (x - 6 == x).  Same steps here, at most 64 of them (|hue| < 3840 degrees behaves like
+                // upstream); a hue still out of range after that is taken as 0 instead of hanging.
+                for (int it = 0; it < 64 && hh < 0; it++) hh += 6;
+                for (int it = 0; it < 64 && hh >= 6; it++) hh -= 6;
+                if (hh < 0 || hh >= 6) hh = 0.f;
                 int sector = (int)std::floor(hh);
                 hh -= sector;
                 if ((unsigned)sector >= 6u) { sector = 0; hh = 0.f; }

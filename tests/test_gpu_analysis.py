@@ -181,6 +181,32 @@ def test_analysis_on_adversarial_flow(ctx, orc):
             o = pts.copy()
             orc.streamline_points(o, f, 0.1, 20, 1.7, variant=variant)
             assert eq(g.cpu().numpy() if hasattr(g, "cpu") else np.asarray(g), o)
+        # colour / display rows on the same field
+        pt0 = np.zeros((h, w, 2), np.float32)
+        ref = pt0.copy()
+        for _ in range(3):
+            orc.get_delta_field(ref, f, 2.0, 1.8)
+        d = torch.as_tensor(pt0).cuda()
+        for _ in range(3):
+            d = ctx.get_delta_field(d, f, 2.0, 1.8)
+        assert eq(d.cpu().numpy(), ref)
+        r, mf = orc.shear_rate_to_color(f, 0.0)
+        g, gmf = ctx.shearRateToColor(f, 0.0)
+        assert eq(np.float32(gmf), np.float32(mf)) and eq(g.cpu().numpy(), r)
+        # hues far outside [0, 360), infinite and NaN: upstream's wrap loop would never end on the infinite
+        # ones; kernel and oracle take at most 64 steps and then hue 0
+        hsv = np.stack([f[..., 0] * 100, np.abs(f[..., 1]), f[..., 0]], -1).astype(np.float32)
+        assert eq(ctx.hsv_to_bgr(hsv).cpu().numpy(), orc.hsv_to_bgr(hsv))
+        ctx.analysis_reset(w, h)
+        for _ in range(3):
+            ctx.streamline_field(f, 2.0, 2, UPPER=1e30)
+        spt, sdist = ctx.streamline_field_state(w, h)
+        assert not np.isfinite(spt).all()
+        for which in (0, 1, 2):
+            img, mx = ctx.streamline_display(which)
+            r, rmx = orc.streamline_display(spt, sdist, which)
+            assert eq(np.float32(mx), np.float32(rmx)) and eq(img.cpu().numpy(), r)
+        assert eq(ctx.streamline_positions().cpu().numpy(), orc.streamline_positions(spt))
 
 
 def test_histogram_random_directions(ctx, orc):
