@@ -447,6 +447,38 @@ def test_parameter_sweep_beyond_the_reference_call_sites(ctx, orc, i):
     assert st["frac_1e3"] >= 0.97 and st["p50"] <= 2e-4
 
 
+def _hostile_images(w, h):
+    rng = np.random.RandomState(1)
+    yy, xx = np.mgrid[0:h, 0:w]
+    return {
+        "noise": (rng.randint(0, 256, (h, w)).astype(np.uint8), rng.randint(0, 256, (h, w)).astype(np.uint8)),
+        "constant": (np.full((h, w), 77, np.uint8), np.full((h, w), 77, np.uint8)),
+        "black to white": (np.zeros((h, w), np.uint8), np.full((h, w), 255, np.uint8)),
+        "checker 1px": ((((xx + yy) & 1) * 255).astype(np.uint8), (((xx + yy + 1) & 1) * 255).astype(np.uint8)),
+        "vertical bars": (((xx // 4 & 1) * 255).astype(np.uint8), (((xx + 2) // 4 & 1) * 255).astype(np.uint8)),
+        "edge": (np.where(xx < w // 2, 0, 255).astype(np.uint8), np.where(xx < w // 2 + 3, 0, 255).astype(np.uint8)),
+    }
+
+
+@pytest.mark.parametrize("name", ["noise", "constant", "black to white", "checker 1px", "vertical bars", "edge"])
+def test_hostile_images(ctx, orc, name):
+    """Uncorrelated noise (flows of tens of pixels: gathers far outside the block's window), textureless and
+    saturated frames (singular 2x2 systems) through three reference parameter sets: finite, and the oracle's values."""
+    a, b = _hostile_images(320, 240)[name]
+    for p in (RC215, MAIN609, AND167):
+        ref = _oracle_flow(orc, a, b, p)
+        got = ctx.calcOpticalFlowFarneback(a, b, None, **p)
+        st = _report("%s win %d" % (name, p["winsize"]), got, ref)
+        assert np.isfinite(got).all() and st["frac_1e3"] >= 0.99
+
+
+def test_noise_clip_1080p_is_finite(ctx):
+    clip = torch.randint(0, 256, (5, 1080, 1920), dtype=torch.uint8, device="cuda")
+    for p in (RC215, MAIN609, AND167):
+        out = ctx.farneback_clip(clip, **p)
+        assert bool(torch.isfinite(out).all())
+
+
 def test_error_codes(ctx):
     from ripcurrents_amd import RcflowError
     a = np.zeros((64, 64), np.uint8)
