@@ -197,7 +197,8 @@ int rcflow_accumulator_read(rc_ctx* ctx, int stream, float* acc /* h*w */);
 /* Replaces streamlines_mat.forEach(streamline_field(...)) ripcurrents.cpp:229-231
  * (ripcurrents_module.cpp:608-648): one particle per pixel, state in the slot.
  * UPPER < 0 means "use the slot's current UPPER" (the value the previous frame's
- * histogram produced, as in the reference's call order). */
+ * histogram produced, as in the reference's call order).  iterations: 0..65536 (the reference
+ * passes 1 or 100), RC_EINVAL beyond -- the loop runs on the device. */
 int rcflow_advect_field_dev(rc_ctx* ctx, int stream, const float* d_flow_xy, size_t flow_step,
                             int w, int h, float dt, int iterations, float UPPER);
 int rcflow_advect_field_read(rc_ctx* ctx, int stream, float* pt_xy /* h*w*2 */,

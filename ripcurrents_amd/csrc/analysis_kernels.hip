@@ -19,6 +19,7 @@
 #include "rc_host.h"
 
 #define RC_BLOCK 256
+#define RC_MAX_ADVECT_ITERATIONS 65536   // a kernel that never returns is a hung GPU, not a slow call
 #define THR_UPPER 0
 #define THR_UPPER2D 1
 #define THR_PROP (1 + RC_HIST_DIRECTIONS)
@@ -819,7 +820,7 @@ extern "C" int rcflow_advect_field_dev(rc_ctx* ctx, int stream, const float* d_f
     if (!s) return RC_EINVAL;
     int rc = check_flow(d_flow, flow_step, w, h);
     if (rc) return rc;
-    if (iterations < 0) return RC_EINVAL;
+    if (iterations < 0 || iterations > RC_MAX_ADVECT_ITERATIONS) return RC_EINVAL;   // the reference passes 1 or 100
     RC_HIP(hipSetDevice(ctx->device));
     if ((rc = analysis_ensure(ctx, *s, w, h, false))) return rc;
     {
@@ -858,7 +859,8 @@ extern "C" int rcflow_advect_points_dev(rc_ctx* ctx, int stream, float* d_pts, i
     if (!s) return RC_EINVAL;
     int rc = check_flow(d_flow, flow_step, w, h);
     if (rc) return rc;
-    if (n < 0 || (n && !d_pts) || iterations < 0 || variant < 0 || variant > 4) return RC_EINVAL;
+    if (n < 0 || (n && !d_pts) || iterations < 0 || iterations > RC_MAX_ADVECT_ITERATIONS || variant < 0 || variant > 4)
+        return RC_EINVAL;
     if (n == 0) return RC_OK;
     RC_HIP(hipSetDevice(ctx->device));
     const float* thr;

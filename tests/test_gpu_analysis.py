@@ -209,6 +209,23 @@ def test_analysis_on_adversarial_flow(ctx, orc):
         assert eq(ctx.streamline_positions().cpu().numpy(), orc.streamline_positions(spt))
 
 
+def test_advection_iteration_count_is_bounded(ctx):
+    """The step loops run on the device: an absurd count is an argument error, not a kernel that never returns."""
+    from ripcurrents_amd import RcflowError
+    w, h = 64, 48
+    f = np.zeros((h, w, 2), np.float32)
+    ctx.analysis_reset(w, h)
+    for bad in (-1, 65537, 2 ** 31 - 1):
+        with pytest.raises(RcflowError) as e:
+            ctx.streamline_field(f, 2.0, bad, UPPER=1.0)
+        assert e.value.code == -1
+        with pytest.raises(RcflowError) as e:
+            ctx.streamline(np.zeros((3, 2), np.float32), f, 0.1, bad, 1.0)
+        assert e.value.code == -1
+    ctx.streamline_field(f, 2.0, 65536, UPPER=1.0)      # zero field: every particle stops at once
+    ctx.sync()
+
+
 def test_histogram_random_directions(ctx, orc):
     """Uniformly random vectors: every wave holds ~64 distinct bins (the slow path of the
     ballot grouping)."""
