@@ -113,7 +113,8 @@ int rcflow_farneback_dev(rc_ctx* ctx, int stream, const uint8_t* d_prev, size_t 
 /* Streaming form of the frame loop ripcurrents.cpp:194-221 (`u_f1.copyTo(u_f2)` at :216):
  * the slot keeps the previous frame's polynomial expansion, so each call does one
  * pyramid + expansion.  The first call after rcflow_stream_reset only primes the state
- * and writes no flow (returns 1 instead of RC_OK). */
+ * and writes no flow (returns 1 instead of RC_OK); so does the first call with a different
+ * frame size or different parameters (the cached expansion belongs to the old ones). */
 int rcflow_push_frame_dev(rc_ctx* ctx, int stream, const uint8_t* d_frame, size_t step,
                           int w, int h, float* d_flow_xy, size_t flow_step,
                           const rc_farneback_params* p);

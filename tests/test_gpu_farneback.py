@@ -479,6 +479,29 @@ def test_noise_clip_1080p_is_finite(ctx):
         assert bool(torch.isfinite(out).all())
 
 
+def test_stream_reprimes_on_parameter_or_size_change(ctx):
+    """push_frame keeps the previous frame's expansion; a call with other parameters or another frame size
+    must not reuse it: it primes again (no flow), and the next flow equals a fresh two-image call."""
+    clip = synth.surf_clip(320, 240, 4, seed=3)
+    small = synth.surf_clip(256, 192, 3, seed=4)
+    npy = lambda x: x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
+    for p2 in (MAIN1119, dict(RC215, poly_n=5, poly_sigma=1.1), dict(RC215, levels=3), dict(RC215, pyr_scale=0.7),
+               dict(RC215, iterations=3)):
+        ctx.stream_reset()
+        assert ctx.push_frame(clip[0], **RC215) is None
+        assert ctx.push_frame(clip[1], **RC215) is not None
+        assert ctx.push_frame(clip[2], **p2) is None
+        got = npy(ctx.push_frame(clip[3], **p2)).copy()
+        assert np.array_equal(got, npy(ctx.calcOpticalFlowFarneback(clip[2], clip[3], None, **p2)))
+    ctx.stream_reset()
+    ctx.push_frame(clip[0], **RC215)
+    ctx.push_frame(clip[1], **RC215)
+    assert ctx.push_frame(small[0], **RC215) is None
+    got = npy(ctx.push_frame(small[1], **RC215)).copy()
+    assert np.array_equal(got, npy(ctx.calcOpticalFlowFarneback(small[0], small[1], None, **RC215)))
+    ctx.stream_reset()
+
+
 def test_error_codes(ctx):
     from ripcurrents_amd import RcflowError
     a = np.zeros((64, 64), np.uint8)
