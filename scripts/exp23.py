@@ -4,7 +4,8 @@ sys.path.insert(0, '.')
 from ripcurrents_amd import synth
 from ripcurrents_amd.api import Context
 name, vals = sys.argv[1], [int(v) for v in sys.argv[2:]]
-W, H, NP = 1920, 1080, 32
+import os
+W, H, NP = 1920, 1080, int(os.environ.get("NP", "32"))
 P = dict(pyr_scale=0.5, levels=2, winsize=3, iterations=2, poly_n=15, poly_sigma=1.2, flags=0)
 frames = synth.surf_clip(W, H, NP + 1, device=torch.device("cuda"))
 flows = torch.empty((NP, H, W, 2), dtype=torch.float32, device="cuda")
