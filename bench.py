@@ -189,8 +189,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "C2 1920x1080 synthetic surf clip, 3 pyramid scales (levels=2), "
                                    "winsize 3, iters 2, poly_n 15, sigma 1.2, flags %d; %d flow fields per "
-                                   "step per GPU from a clip of one more frame (every frame expanded once: 33 expansions per 32 fields); + flow histogram"
-                                   % (params["flags"], args.pairs),
+                                   "step per GPU from a clip of one more frame (every frame expanded once: %d expansions); "
+                                   "+ flow histogram" % (params["flags"], args.pairs, args.pairs + 1),
                        "pairs_per_step": args.pairs, "segments": world,
                        "collective": ("all_reduce int32[1887] per step" + ("" if args.sync_collective else ", overlapped with the next step")) if world > 1 else "none"},
             "survey_model": {"bytes_per_frame": model_b,
