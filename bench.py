@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--no-roof", action="store_true", help="skip the measured memory roof (read/fill/copy microbench)")
     ap.add_argument("--cpu-pairs", type=int, default=6)
     ap.add_argument("--sync-collective", action="store_true", help="N>1: all-reduce and thresholds inside the step (no one-step pipelining)")
+    ap.add_argument("--clip-per-step", action="store_true", help="every step is an independent clip of pairs + 1 frames (pairs + 1 expansions)")
     ap.add_argument("--gaussian", action="store_true", help="main.cpp:264 variant (flags=256)")
     args = ap.parse_args()
 
@@ -122,8 +123,24 @@ def main():
         while pending:
             ctx.thresholds_from_words(pending.pop(0).wait())
 
+    # The segment is a stream: every step pushes the next `pairs` frames (rcflow_push_clip_dev), the slot keeps
+    # the last frame's expansion, so every frame is expanded exactly once (SURVEY 8(d)'s streaming model).  The
+    # synthetic clip is played forwards, then backwards, then forwards ...: consecutive frames are always
+    # neighbours in the clip.  --clip-per-step restores independent clips of pairs + 1 frames per step.
+    fwd = frames[1:]
+    bwd = frames.flip(0)[1:].contiguous()
+    if not args.clip_per_step:
+        ctx.stream_reset()
+        ctx.push_clip(frames[0:1], flows, **params)          # primes the stream, no flow
+    nstep = [0]
+
     def step():
-        ctx.farneback_clip(frames, flows, **params)
+        if args.clip_per_step:
+            ctx.farneback_clip(frames, flows, **params)
+        else:
+            got = ctx.push_clip(fwd if nstep[0] % 2 == 0 else bwd, flows, **params)
+            assert got.shape[0] == args.pairs
+            nstep[0] += 1
         ctx.histogram_accumulate_clip(flows)
         if world > 1:
             # global flow histogram: integer sum over RCCL, order independent; every
@@ -189,8 +206,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": "C2 1920x1080 synthetic surf clip, 3 pyramid scales (levels=2), "
                                    "winsize 3, iters 2, poly_n 15, sigma 1.2, flags %d; %d flow fields per "
-                                   "step per GPU from a clip of one more frame (every frame expanded once: %d expansions); "
-                                   "+ flow histogram" % (params["flags"], args.pairs, args.pairs + 1),
+                                   "step per GPU, %s; + flow histogram"
+                                   % (params["flags"], args.pairs,
+                                      "an independent clip of %d frames per step (%d expansions)" % (args.pairs + 1, args.pairs + 1)
+                                      if args.clip_per_step else
+                                      "the next %d frames of a continuing segment per step (streaming model: every frame "
+                                      "expanded once; the clip is played forwards and backwards)" % args.pairs),
                        "pairs_per_step": args.pairs, "segments": world,
                        "collective": ("all_reduce int32[1887] per step" + ("" if args.sync_collective else ", overlapped with the next step")) if world > 1 else "none"},
             "survey_model": {"bytes_per_frame": model_b,

@@ -118,6 +118,13 @@ int rcflow_farneback_dev(rc_ctx* ctx, int stream, const uint8_t* d_prev, size_t 
 int rcflow_push_frame_dev(rc_ctx* ctx, int stream, const uint8_t* d_frame, size_t step,
                           int w, int h, float* d_flow_xy, size_t flow_step,
                           const rc_farneback_params* p);
+/* Batched form of the same stream: the nframes frames continue the slot's stream, every frame is expanded
+ * once however the segment is cut into calls.  Returns the number of flow fields written to d_flows[0..):
+ * nframes if the stream was primed (flow 0 = last frame of the previous call -> d_frames[0]), nframes - 1 if
+ * this call primed it; negative RC_E* on error.  Interoperates with rcflow_push_frame_dev. */
+int rcflow_push_clip_dev(rc_ctx* ctx, int stream, const uint8_t* d_frames, size_t frame_stride, size_t step,
+                         int nframes, int w, int h, float* d_flows_xy, size_t flow_frame_stride,
+                         size_t flow_step, const rc_farneback_params* p);
 int rcflow_stream_reset(rc_ctx* ctx, int stream);
 /* A whole resident clip: nframes frames -> nframes-1 flow fields (pair t = frames t,t+1),
  * processed `chunk` pairs per launch.  The bench path. */

@@ -49,6 +49,7 @@ SIGNATURES = {
     "rcflow_push_frame_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz, _pp],
     "rcflow_stream_reset": [_vp, _i],
     "rcflow_farneback_clip_dev": [_vp, _i, _vp, _sz, _sz, _i, _i, _i, _vp, _sz, _sz, _pp],
+    "rcflow_push_clip_dev": [_vp, _i, _vp, _sz, _sz, _i, _i, _i, _vp, _sz, _sz, _pp],
     "rcflow_push_batch_dev": [_vp, _i, _vp, _sz, _sz, _i, _i, _i, _vp, _sz, _sz, _pp, _i],
     "rcflow_batch_reset": [_vp, _i],
     "rcflow_level_geometry": [_i, _i, _d, _i, _i, C.POINTER(_i), C.POINTER(_i)],

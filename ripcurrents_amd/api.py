@@ -168,6 +168,23 @@ class Context:
                                                    self._ptr(flow), flow.stride(0) * 4, C.byref(p)))
         return None if rc == 1 else flow
 
+    def push_clip(self, frames, flows=None, stream=0, **kw):
+        """The next [T,H,W] frames of the slot's stream in one call (rcflow_push_clip_dev): every frame is
+        expanded once however the segment is cut into calls.  Returns the flow fields written ([T,H,W,2] when
+        the stream was primed -- flow 0 runs from the previous call's last frame to frames[0] -- else [T-1,...])."""
+        frames = self._dev(frames, torch.uint8)
+        T, h, w = frames.shape
+        p = _params(kw.get("pyr_scale", 0.5), kw.get("levels", 2), kw.get("winsize", 3),
+                    kw.get("iterations", 2), kw.get("poly_n", 15), kw.get("poly_sigma", 1.2),
+                    kw.get("flags", 0))
+        if flows is None:
+            flows = torch.empty((T, h, w, 2), dtype=torch.float32, device=frames.device)
+        self._bind(stream)
+        n = check(self._lib.rcflow_push_clip_dev(
+            self._h, stream, self._ptr(frames), frames.stride(0), frames.stride(1), T, w, h,
+            self._ptr(flows), flows.stride(0) * 4, flows.stride(1) * 4, C.byref(p)))
+        return flows[:n]
+
     def stream_reset(self, stream=0):
         check(self._lib.rcflow_stream_reset(self._h, stream))
 

@@ -759,6 +759,57 @@ extern "C" int rcflow_push_frame_dev(rc_ctx* ctx, int stream, const uint8_t* d_f
     return RC_OK;
 }
 
+// Streaming form of the clip call: the frames CONTINUE the slot's stream (the one rcflow_push_frame_dev
+// feeds), so a segment processed in batches expands every frame exactly once.  Returns the number of flow
+// fields written to d_flows[0 ..): nframes when the stream was primed (flow 0 = previous call's last frame ->
+// d_frames[0]), nframes - 1 when this call primed it (first call after rcflow_stream_reset, or another size /
+// other parameters); negative RC_E* on error.
+extern "C" int rcflow_push_clip_dev(rc_ctx* ctx, int stream, const uint8_t* d_frames, size_t frame_stride, size_t step,
+                                    int nframes, int w, int h, float* d_flows, size_t flow_frame_stride,
+                                    size_t flow_step, const rc_farneback_params* p) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !d_frames || nframes < 1) { if (s) rc_set_error("bad clip arguments"); return RC_EINVAL; }
+    if (step < (size_t)w || (nframes > 1 && frame_stride < step * (size_t)(h - 1) + w)) {
+        rc_set_error("clip strides smaller than a frame");
+        return RC_EINVAL;
+    }
+    RC_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_plan(ctx, *s, w, h, p, ctx->chunk);          // a new size / parameter set drops `primed`
+    if (rc) return rc;
+    s->batch_primed = 0;
+    const int C = s->plan.chunk, ns = s->plan.nslots;
+    int t = 0, s0 = s->cur_slot;
+    if (!s->primed) {
+        if ((rc = expand_frames(ctx, *s, d_frames, 0, step, 1, 0))) return rc;
+        s->primed = 1;
+        s->cur_slot = s0 = 0;
+        t = 1;
+    }
+    const int nflows = nframes - t;
+    if (nflows > 0 && (!d_flows || flow_step < (size_t)w * 8 ||
+                       (nflows > 1 && flow_frame_stride < flow_step * (size_t)(h - 1) + (size_t)w * 8))) {
+        rc_set_error("bad flow buffer");
+        return RC_EINVAL;
+    }
+    for (int done = 0; t < nframes;) {
+        const int np = nframes - t < C ? nframes - t : C;
+        if ((rc = expand_frames(ctx, *s, d_frames + (size_t)t * frame_stride, frame_stride, step, np, (s0 + 1) % ns))) {
+            s->primed = 0;
+            return rc;
+        }
+        if ((rc = compute_flows(ctx, *s, np, s0, (float*)((char*)d_flows + (size_t)done * flow_frame_stride),
+                                flow_frame_stride, flow_step))) {
+            s->primed = 0;
+            return rc;
+        }
+        s0 = (s0 + np) % ns;
+        s->cur_slot = s0;
+        t += np;
+        done += np;
+    }
+    return nflows;
+}
+
 extern "C" int rcflow_farneback_clip_dev(rc_ctx* ctx, int stream, const uint8_t* d_frames, size_t frame_stride,
                                          size_t step, int nframes, int w, int h, float* d_flows,
                                          size_t flow_frame_stride, size_t flow_step,

@@ -502,6 +502,39 @@ def test_stream_reprimes_on_parameter_or_size_change(ctx):
     ctx.stream_reset()
 
 
+@pytest.mark.parametrize("p", [RC215, MAIN1119])
+def test_push_clip_continues_the_stream(ctx, p):
+    """A segment pushed in uneven batches (rcflow_push_clip_dev), mixed with single push_frame calls, gives the
+    flow fields of one clip call over the whole segment: the stream carries over, every frame is expanded once."""
+    clip = torch.as_tensor(synth.surf_clip(200, 150, 12, seed=6)).cuda()
+    whole = ctx.farneback_clip(clip, **p).cpu().numpy()                      # 11 fields
+    for chunk in (32, 2):
+        ctx.set_option("chunk", chunk)
+        ctx.stream_reset()
+        got = []
+        a = ctx.push_clip(clip[0:4], **p)                 # primes: 3 fields
+        assert a.shape[0] == 3
+        got += [a.cpu().numpy()]
+        b = ctx.push_clip(clip[4:5], **p)                 # one frame: 1 field
+        assert b.shape[0] == 1
+        got += [b.cpu().numpy()]
+        c = ctx.push_frame(clip[5], **p)                  # the single-frame call continues the same stream
+        got += [c.cpu().numpy()[None]]
+        d = ctx.push_clip(clip[6:12], **p)                # 6 fields
+        assert d.shape[0] == 6
+        got += [d.cpu().numpy()]
+        assert np.array_equal(np.concatenate(got), whole)
+    ctx.set_option("chunk", 32)
+    # a first call of one frame only primes
+    ctx.stream_reset()
+    assert ctx.push_clip(clip[0:1], **p).shape[0] == 0
+    assert np.array_equal(ctx.push_clip(clip[1:3], **p).cpu().numpy(), whole[:2])
+    # other parameters: primes again
+    q = dict(p, iterations=p["iterations"] + 1)
+    assert ctx.push_clip(clip[3:6], **q).shape[0] == 2
+    ctx.stream_reset()
+
+
 def test_error_codes(ctx):
     from ripcurrents_amd import RcflowError
     a = np.zeros((64, 64), np.uint8)
