@@ -9,7 +9,7 @@
 // Like upstream it (re)allocates `flow` as CV_32FC2 of prev's size and throws cv::Exception
 // on bad arguments.  UMat arguments are mapped with getMat(), i.e. the host-pointer entry point
 // (copy in, compute, copy out); for a zero-copy path keep frames on the device and call
-// rcflow_push_frame_dev / rcflow_farneback_clip_dev directly.
+// rcflow_push_frame_dev / rcflow_push_clip_dev / rcflow_farneback_clip_dev directly.
 #pragma once
 
 #if __has_include(<opencv2/core.hpp>)
