@@ -83,6 +83,29 @@ class Pipeline {
     // cv::calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, iterations,
     // poly_n, poly_sigma, flags): 8UC1 in, CV_32FC2 out (flow.data may be null: the field then
     // only stays resident for the analysis calls).
+    // The frame loop itself (ripcurrents.cpp:194-221: capture, calcOpticalFlowFarneback(u_f2, u_f1, ...),
+    // u_f1.copyTo(u_f2)) with the previous frame kept on the device: one upload and one pyramid + expansion
+    // per frame (rcflow_push_frame_dev).  Returns false for the call that primes the stream (the first one, or
+    // the first with other parameters): no flow yet.  The flow equals calcOpticalFlowFarneback(previous, frame).
+    bool pushFrame(const Mat& frame, Mat& flow, double pyr_scale, int levels, int winsize, int iterations, int poly_n,
+                   double poly_sigma, int flags) {
+        if (frame.empty() || frame.channels != 1 || frame.elem != 1 || frame.cols != w_ || frame.rows != h_)
+            throw Error(RC_EINVAL, "pushFrame: frame must be 8UC1 of the pipeline's size");
+        uint8_t* df = (uint8_t*)d_frames_;
+        hip_check(hipMemcpy2D(df, w_, frame.data, frame.step, w_, h_, hipMemcpyHostToDevice), "upload frame");
+        rc_farneback_params p = {pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags};
+        const int rc = rcflow_push_frame_dev(ctx_, 0, df, w_, w_, h_, (float*)d_flow_, (size_t)w_ * 8, &p);
+        check(rc);
+        check(rcflow_sync(ctx_, 0));
+        if (rc == 1) return false;
+        if (flow.data) {
+            if (flow.rows != h_ || flow.cols != w_ || flow.channels != 2 || flow.elem != 4)
+                throw Error(RC_EINVAL, "flow must be CV_32FC2 of the frame size");
+            hip_check(hipMemcpy2D(flow.data, flow.step, d_flow_, (size_t)w_ * 8, (size_t)w_ * 8, h_, hipMemcpyDeviceToHost), "download flow");
+        }
+        return true;
+    }
+
     void calcOpticalFlowFarneback(const Mat& prev, const Mat& next, Mat& flow, double pyr_scale, int levels,
                                   int winsize, int iterations, int poly_n, double poly_sigma, int flags) {
         if (prev.empty() || next.empty() || prev.rows != next.rows || prev.cols != next.cols ||

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../include/rcflow_module.hpp"
@@ -115,6 +116,22 @@ int main() {
     for (int i = 0; i < on; i++) REQUIRE(streak.vertices[i].x == overts[2 * i] && streak.vertices[i].y == overts[2 * i + 1]);
 
     // error behaviour: bad arguments throw (the reference's cv:: calls throw cv::Exception)
+    // the frame loop with the previous frame kept on the device: same flow as the two-image call
+    {
+        std::vector<uint8_t> a((size_t)XDIM * YDIM), b((size_t)XDIM * YDIM), c((size_t)XDIM * YDIM);
+        make_frame(a, 11); make_frame(b, 12); make_frame(c, 13);
+        std::vector<float> fl((size_t)XDIM * YDIM * 2), ref((size_t)XDIM * YDIM * 2);
+        rc::Mat ma(YDIM, XDIM, 1, 1, a.data()), mb(YDIM, XDIM, 1, 1, b.data()), mc(YDIM, XDIM, 1, 1, c.data());
+        rc::Mat mfl(YDIM, XDIM, 2, 4, fl.data()), mref(YDIM, XDIM, 2, 4, ref.data());
+        REQUIRE(rcflow_stream_reset(pipe.context(), 0) == 0);
+        REQUIRE(!pipe.pushFrame(ma, mfl, 0.5, 2, 3, 2, 15, 1.2, 0));          // primes
+        REQUIRE(pipe.pushFrame(mb, mfl, 0.5, 2, 3, 2, 15, 1.2, 0));
+        REQUIRE(pipe.pushFrame(mc, mfl, 0.5, 2, 3, 2, 15, 1.2, 0));
+        pipe.calcOpticalFlowFarneback(mb, mc, mref, 0.5, 2, 3, 2, 15, 1.2, 0);
+        REQUIRE(memcmp(fl.data(), ref.data(), fl.size() * sizeof(float)) == 0);
+        REQUIRE(!pipe.pushFrame(ma, mfl, 0.5, 2, 10, 3, 15, 1.2, 256));      // other parameters: primes again
+    }
+
     bool threw = false;
     try {
         rc::Mat prev(YDIM, XDIM, 1, 1, f2.data()), bad;
