@@ -101,22 +101,22 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist(const float* flow0, siz
     for (int i = threadIdx.x; i < RC_HIST_DIRECTIONS * RC_HIST_BINS; i += RC_BLOCK) lh[i] = 0;
     __syncthreads();
     const int w2 = (w + 1) >> 1;
-    const long long total = (long long)w2 * h;
-    const long long span = (long long)gridDim.x * RC_BLOCK;
+    const int total = w2 * h;                 // the entry point bounds w * h
+    const int span = (int)gridDim.x * RC_BLOCK;
     // every lane runs the same number of rounds so the ballots see whole waves; four loads are in
     // flight per thread before the first is consumed
-    const long long rounds = (total + span - 1) / span;
+    const int rounds = (total + span - 1) / span;
     // (row, pair-in-row) of the thread's item, advanced by `span` items per round without a division
-    const long long i0 = (long long)blockIdx.x * RC_BLOCK + threadIdx.x;
-    int yy = (int)(i0 / w2), xx = (int)(i0 - (long long)yy * w2);
-    const int dy = (int)(span / w2), dx = (int)(span - (long long)dy * w2);
+    const int i0 = (int)blockIdx.x * RC_BLOCK + threadIdx.x;
+    int yy = i0 / w2, xx = i0 - yy * w2;
+    const int dy = span / w2, dx = span - dy * w2;
     constexpr int UNR = 4;
     // The next batch's loads are issued before the current batch is binned, so that a wave never computes
     // with nothing in flight (-4 %; the loads alone take 84 us per 32 1080p fields, the kernel 145: the
     // rest is instruction issue -- correctly rounded sqrt and divisions, ballots -- not memory)
     float4 vn[UNR];
     int nn[UNR];
-    auto load_batch = [&](long long it0) {
+    auto load_batch = [&](int it0) {
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             nn[u] = 0;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist(const float* flow0, siz
         }
     };
     load_batch(0);
-    for (long long it0 = 0; it0 < rounds; it0 += UNR) {
+    for (int it0 = 0; it0 < rounds; it0 += UNR) {
         float4 v[UNR];
         int nv[UNR];
 #pragma unroll
@@ -688,6 +688,7 @@ extern "C" int rcflow_histogram_clip_dev(rc_ctx* ctx, int stream, const float* d
     if (rc) return rc;
     if (count < 1 || count > 65535 || (count > 1 && flow_frame_stride < flow_step * (size_t)(h - 1) + (size_t)w * 8))
         return RC_EINVAL;
+    if ((long long)w * h > 0x3fffffffll) { rc_set_error("frame too large for the histogram kernel's 32-bit item index"); return RC_ESIZE; }
     RC_HIP(hipSetDevice(ctx->device));
     if ((rc = analysis_ensure(ctx, *s, w, h, false))) return rc;
     {
