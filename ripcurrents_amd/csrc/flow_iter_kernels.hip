@@ -1068,8 +1068,8 @@ __device__ __forceinline__ void rc_hsum3_dpp(float (&g)[5], const float (&V)[5])
         "v_add_f32_dpp %4, %9, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
         : "v"(V[0]), "v"(V[1]), "v"(V[2]), "v"(V[3]), "v"(V[4]));
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %5, %10 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    // (no wait states here: the DPP operand is V again, written at least five instructions ago)
+    asm("v_add_f32_dpp %0, %5, %10 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %1, %6, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %2, %7, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %3, %8, %13 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -1090,8 +1090,8 @@ __device__ __forceinline__ void rc_hpair_dpp(float (&s)[5], const float (&V)[5])
         "v_mov_b32_dpp %4, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
         : "v"(V[0]), "v"(V[1]), "v"(V[2]), "v"(V[3]), "v"(V[4]));
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %5, %10 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    // (no wait states here: the DPP operand is V again, written at least five instructions ago)
+    asm("v_add_f32_dpp %0, %5, %10 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %1, %6, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %2, %7, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %3, %8, %13 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
