@@ -80,7 +80,14 @@ int rcflow_sync(rc_ctx* ctx, int stream);
  * own non-blocking stream. */
 int rcflow_set_hip_stream(rc_ctx* ctx, int stream, void* hip_stream);
 int rcflow_use_own_stream(rc_ctx* ctx, int stream);
-/* Tunables: "chunk" = frame pairs per launch in clip mode (default 32);
+/* "exact" (-1 | 0 | 1, default -1): 1 runs every Farneback stage in the operation order of OpenCV's CPU path
+ * (float / double exactly where optflow.cpp has them, no fused multiply-adds): the flow field is then
+ * bit-identical to the CPU path (tests/test_gpu_exact.py), at 2-15x the time.  0 always takes the fast kernels
+ * (reordered fp32 sums: within SURVEY 8(d)'s tolerance wherever the 2x2 system is well conditioned).  -1 picks
+ * exact only where the fast kernels cannot hold that tolerance: the near-pointwise windows (Gaussian winsize < 7,
+ * i.e. main.cpp:264, :742, ripcurrents_module.cpp:712, main_old.cpp:324, and winsize 1), whose determinant
+ * vanishes on smooth regions so that any rounding difference is amplified from scale to scale.
+ * Tunables: "chunk" = frame pairs per launch in clip mode (default 32);
  * "exact_taps" = 1 keeps every polynomial-expansion tap instead of dropping taps whose
  * total weight is below 1e-8 of the kernel mass (default 0);
  * "fuse_iters" = 0 runs every Farneback iteration as its own launch instead of two per

@@ -210,33 +210,47 @@ void prepare_gaussian(int n, double sigma, float* g, float* xg, float* xxg, doub
     G[2][2] = G[0][3] = G[0][4] = G[3][0] = G[4][0] = G[1][1];
     G[4][4] = G[3][3];
     G[3][4] = G[4][3] = G[5][5];
-    // invG = G.inv(DECOMP_CHOLESKY): G is SPD; Gauss-Jordan in double gives the same
-    // inverse to ~1e-16 relative.
-    double A[6][12];
+    // invG = G.inv(DECOMP_CHOLESKY): cv::invert -> setIdentity(dst); hal::Cholesky64f(G, dst)
+    // (core/src/matrix_decomp.cpp CholImpl<double>; a 6x6 is below the LAPACK threshold of
+    // hal_internal.cpp).  L keeps 1/sqrt(pivot) on its diagonal; forward then backward
+    // substitution on the identity, every partial sum in double.
+    double L[6][6], B[6][6];
     for (int i = 0; i < 6; i++)
         for (int j = 0; j < 6; j++) {
-            A[i][j] = G[i][j];
-            A[i][j + 6] = i == j ? 1. : 0.;
+            L[i][j] = G[i][j];
+            B[i][j] = i == j ? 1. : 0.;
         }
-    for (int c = 0; c < 6; c++) {
-        int p = c;
-        for (int r = c + 1; r < 6; r++)
-            if (std::fabs(A[r][c]) > std::fabs(A[p][c])) p = r;
-        if (p != c)
-            for (int j = 0; j < 12; j++) std::swap(A[p][j], A[c][j]);
-        double d = 1. / A[c][c];
-        for (int j = 0; j < 12; j++) A[c][j] *= d;
-        for (int r = 0; r < 6; r++) {
-            if (r == c) continue;
-            double f = A[r][c];
-            if (f != 0)
-                for (int j = 0; j < 12; j++) A[r][j] -= f * A[c][j];
+    for (int i = 0; i < 6; i++) {
+        double s;
+        int j, k;
+        for (j = 0; j < i; j++) {
+            s = L[i][j];
+            for (k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+            L[i][j] = s * L[j][j];
         }
+        s = L[i][i];
+        for (k = 0; k < j; k++) {
+            double t = L[i][k];
+            s -= t * t;
+        }
+        L[i][i] = 1. / std::sqrt(s);
     }
-    ig11 = A[1][1 + 6];
-    ig03 = A[0][3 + 6];
-    ig33 = A[3][3 + 6];
-    ig55 = A[5][5 + 6];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+            double s = B[i][j];
+            for (int k = 0; k < i; k++) s -= L[i][k] * B[k][j];
+            B[i][j] = s * L[i][i];
+        }
+    for (int i = 5; i >= 0; i--)
+        for (int j = 0; j < 6; j++) {
+            double s = B[i][j];
+            for (int k = 5; k > i; k--) s -= L[k][i] * B[k][j];
+            B[i][j] = s * L[i][i];
+        }
+    ig11 = B[1][1];
+    ig03 = B[0][3];
+    ig33 = B[3][3];
+    ig55 = B[5][5];
 }
 
 // FarnebackPolyExp: R = (y, x, y^2, x^2, xy) coefficients, 5 interleaved floats/px.
@@ -366,8 +380,9 @@ void update_matrices(const float* R0_, const float* R1, const float* flow_, floa
 }
 
 // FarnebackUpdateFlow_Blur (box window, double running sums, literal stripe logic)
+// gout (optional, 3 floats per pixel): the window values (g11, g12, g22) the solve used.
 void update_flow_blur(const float* R0, const float* R1, float* flow_, float* matM, int width,
-                      int height, int block_size, bool update) {
+                      int height, int block_size, bool update, float* gout = nullptr) {
     int m = block_size / 2;
     int y0 = 0, y1;
     int min_update_stripe = std::max((1 << 10) / width, block_size);
@@ -416,6 +431,10 @@ void update_flow_blur(const float* R0, const float* R1, float* flow_, float* mat
             double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
             flow[x * 2] = (float)((g11_ * h2_ - g12_ * h1_) * idet);
             flow[x * 2 + 1] = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+            if (gout) {
+                float* go = gout + ((size_t)y * width + x) * 3;
+                go[0] = (float)g11_; go[1] = (float)g12_; go[2] = (float)g22_;
+            }
         }
         y1 = y == height - 1 ? height : y - block_size;
         if (update && (y1 == height || y1 >= y0 + min_update_stripe)) {
@@ -427,7 +446,7 @@ void update_flow_blur(const float* R0, const float* R1, float* flow_, float* mat
 
 // FarnebackUpdateFlow_GaussianBlur (float separable window, literal stripe logic)
 void update_flow_gaussian(const float* R0, const float* R1, float* flow_, float* matM,
-                          int width, int height, int block_size, bool update) {
+                          int width, int height, int block_size, bool update, float* gout = nullptr) {
     int m = block_size / 2;
     int y0 = 0, y1;
     int min_update_stripe = std::max((1 << 10) / width, block_size);
@@ -475,6 +494,10 @@ void update_flow_gaussian(const float* R0, const float* R1, float* flow_, float*
             double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
             flow[x * 2] = (float)((g11 * h2 - g12 * h1) * idet);
             flow[x * 2 + 1] = (float)((g22 * h1 - g12 * h2) * idet);
+            if (gout) {
+                float* go = gout + ((size_t)y * width + x) * 3;
+                go[0] = (float)g11; go[1] = (float)g12; go[2] = (float)g22;
+            }
         }
         y1 = y == height - 1 ? height : y - block_size;
         if (update && (y1 == height || y1 >= y0 + min_update_stripe)) {
@@ -589,10 +612,10 @@ int orc_update_flow_gaussian(const float* R0, const float* R1, float* flow, floa
 
 // FarnebackOpticalFlowImpl::calc (CPU path; OPTFLOW_USE_INITIAL_FLOW is never used by
 // the reference and is rejected here)
-int orc_farneback_u8(const uint8_t* prev, size_t prev_step, const uint8_t* next,
-                     size_t next_step, int w, int h, float* flow0, size_t flow_step,
-                     double pyr_scale, int levels, int winsize, int iters, int poly_n,
-                     double poly_sigma, int flags, int nthreads) {
+int orc_farneback_u8_ex(const uint8_t* prev, size_t prev_step, const uint8_t* next,
+                        size_t next_step, int w, int h, float* flow0, size_t flow_step,
+                        double pyr_scale, int levels, int winsize, int iters, int poly_n,
+                        double poly_sigma, int flags, int nthreads, const orc_farneback_diag* dg) {
     if (!prev || !next || !flow0 || w <= 0 || h <= 0 || !(pyr_scale < 1) || pyr_scale <= 0 ||
         poly_n < 1 || winsize < 1 || iters < 0 || (flags & ~ORC_FARNEBACK_GAUSSIAN))
         return -1;
@@ -618,14 +641,40 @@ int orc_farneback_u8(const uint8_t* prev, size_t prev_step, const uint8_t* next,
             polyexp(I.data(), width, height, poly_n, poly_sigma, R[i].data(), nthreads);
         }
         update_matrices(R[0].data(), R[1].data(), flow.data(), M.data(), width, height, 0, height);
+        const bool want_g = dg && (dg->det_min || (k == 0 && dg->g_last));
+        std::vector<float> gbuf(want_g ? (size_t)width * height * 3 : 0);
+        std::vector<float> dmin(dg && dg->det_min ? (size_t)width * height : 0, FLT_MAX);
         for (int i = 0; i < iters; i++) {
             if (flags & ORC_FARNEBACK_GAUSSIAN)
                 update_flow_gaussian(R[0].data(), R[1].data(), flow.data(), M.data(), width,
-                                     height, winsize, i < iters - 1);
+                                     height, winsize, i < iters - 1, want_g ? gbuf.data() : nullptr);
             else
                 update_flow_blur(R[0].data(), R[1].data(), flow.data(), M.data(), width, height,
-                                 winsize, i < iters - 1);
+                                 winsize, i < iters - 1, want_g ? gbuf.data() : nullptr);
+            for (size_t p = 0; p < dmin.size(); p++) {
+                const float* go = gbuf.data() + p * 3;
+                dmin[p] = std::min(dmin[p], (float)((double)go[0] * go[2] - (double)go[1] * go[1]));
+            }
         }
+        if (dg && dg->g_last && k == 0 && iters > 0)
+            std::memcpy(dg->g_last, gbuf.data(), sizeof(float) * gbuf.size());
+        if (dg && dg->det_min && iters > 0) {
+            // a full-resolution pixel inherits the worst determinant of the 3x3 block around its
+            // ancestor at this scale (the footprint of the bilinear up-sampling and of a small window)
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++) {
+                    int ax = std::min((int)((x + 0.5) * g.scale), width - 1);
+                    int ay = std::min((int)((y + 0.5) * g.scale), height - 1);
+                    float v = FLT_MAX;
+                    for (int yy = std::max(ay - 1, 0); yy <= std::min(ay + 1, height - 1); yy++)
+                        for (int xx = std::max(ax - 1, 0); xx <= std::min(ax + 1, width - 1); xx++)
+                            v = std::min(v, dmin[(size_t)yy * width + xx]);
+                    float& o = dg->det_min[(size_t)y * w + x];
+                    o = (k == levels) ? v : std::min(o, v);
+                }
+        }
+        if (dg && k < ORC_MAX_DIAG_LEVELS && dg->level_flow[k])
+            std::memcpy(dg->level_flow[k], flow.data(), sizeof(float) * flow.size());
         prevFlow.swap(flow);
         pw = width;
         ph = height;
@@ -634,6 +683,14 @@ int orc_farneback_u8(const uint8_t* prev, size_t prev_step, const uint8_t* next,
         std::memcpy((char*)flow0 + y * flow_step, prevFlow.data() + (size_t)y * w * 2,
                     sizeof(float) * 2 * w);
     return 0;
+}
+
+int orc_farneback_u8(const uint8_t* prev, size_t prev_step, const uint8_t* next,
+                     size_t next_step, int w, int h, float* flow0, size_t flow_step,
+                     double pyr_scale, int levels, int winsize, int iters, int poly_n,
+                     double poly_sigma, int flags, int nthreads) {
+    return orc_farneback_u8_ex(prev, prev_step, next, next_step, w, h, flow0, flow_step, pyr_scale,
+                               levels, winsize, iters, poly_n, poly_sigma, flags, nthreads, nullptr);
 }
 
 }  // extern "C"

@@ -59,6 +59,45 @@ def farneback(prev, nxt, pyr_scale=0.5, levels=2, winsize=3, iters=2, poly_n=15,
     return flow
 
 
+class _Diag(C.Structure):
+    _fields_ = [("g_last", C.POINTER(C.c_float)), ("det_min", C.POINTER(C.c_float)),
+                ("level_flow", C.POINTER(C.c_float) * 12)]
+
+
+def farneback_diag(prev, nxt, pyr_scale=0.5, levels=2, winsize=3, iters=2, poly_n=15,
+                   poly_sigma=1.2, flags=0, nthreads=1, level_flows=False):
+    """farneback() plus the conditioning diagnostics of orc_farneback_u8_ex:
+    returns (flow, det_last, det_min[, level_flows]) with det_last = g11*g22 - g12^2 of the final
+    solve at every pixel (float64) and det_min its minimum over the pixel's whole coarse-to-fine path."""
+    prev = np.ascontiguousarray(prev, dtype=np.uint8)
+    nxt = np.ascontiguousarray(nxt, dtype=np.uint8)
+    h, w = prev.shape
+    flow = np.zeros((h, w, 2), np.float32)
+    g_last = np.zeros((h, w, 3), np.float32)
+    det_min = np.zeros((h, w), np.float32)
+    d = _Diag()
+    d.g_last = _p(g_last)
+    d.det_min = _p(det_min)
+    lf = []
+    if level_flows:
+        L = level_geometry(w, h, pyr_scale, levels, 0)["levels"]
+        for k in range(L + 1):
+            g = level_geometry(w, h, pyr_scale, levels, k)
+            lf.append(np.zeros((g["h"], g["w"], 2), np.float32))
+            d.level_flow[k] = _p(lf[k])
+    fn = lib().orc_farneback_u8_ex
+    fn.restype = C.c_int
+    rc = fn(_p(prev, C.c_uint8), C.c_size_t(prev.strides[0]), _p(nxt, C.c_uint8),
+            C.c_size_t(nxt.strides[0]), w, h, _p(flow), C.c_size_t(flow.strides[0]),
+            C.c_double(pyr_scale), levels, winsize, iters, poly_n, C.c_double(poly_sigma), flags,
+            nthreads, C.byref(d))
+    if rc != 0:
+        raise ValueError("orc_farneback_u8_ex rejected its arguments (rc=%d)" % rc)
+    g = g_last.astype(np.float64)
+    det_last = g[..., 0] * g[..., 2] - g[..., 1] ** 2
+    return (flow, det_last, det_min, lf) if level_flows else (flow, det_last, det_min)
+
+
 def level_geometry(w, h, pyr_scale, levels, k):
     wk, hk, ks = C.c_int(), C.c_int(), C.c_int()
     sg = C.c_double()

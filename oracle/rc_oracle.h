@@ -37,6 +37,25 @@ int orc_farneback_u8(const uint8_t* prev, size_t prev_step, const uint8_t* next,
                      double pyr_scale, int levels, int winsize, int iters, int poly_n,
                      double poly_sigma, int flags, int nthreads);
 
+/* The same call with diagnostics for the parity tests (the tolerance is stated on
+ * pixels whose 2x2 system is well conditioned).  Any pointer may be NULL.
+ *   g_last      h*w*3  the window values (g11, g12, g22) of the LAST iteration at scale 0, i.e.
+ *                      the matrix the final solve inverted (box window: already scaled by 1/winsize^2)
+ *   det_min     h*w    min over every scale and iteration of g11*g22 - g12^2 over the 3x3 block
+ *                      around the pixel's ancestor at that scale (conditioning of the whole
+ *                      coarse-to-fine path that produced the pixel)
+ *   level_flow  [k]    w_k*h_k*2: the flow at the end of scale k (before up-sampling) */
+#define ORC_MAX_DIAG_LEVELS 12
+typedef struct orc_farneback_diag {
+    float* g_last;
+    float* det_min;
+    float* level_flow[ORC_MAX_DIAG_LEVELS];
+} orc_farneback_diag;
+int orc_farneback_u8_ex(const uint8_t* prev, size_t prev_step, const uint8_t* next,
+                        size_t next_step, int w, int h, float* flow, size_t flow_step,
+                        double pyr_scale, int levels, int winsize, int iters, int poly_n,
+                        double poly_sigma, int flags, int nthreads, const orc_farneback_diag* diag);
+
 /* number of pyramid scales actually used (levels cropped by min_size=32) and
  * the size of scale k; returns cropped `levels` (scales are k=0..levels). */
 int orc_level_geometry(int w, int h, double pyr_scale, int levels, int k, int* wk,

@@ -1,0 +1,271 @@
+// exact_kernels.hip -- option "exact": the Farneback stages in the operation order of OpenCV's CPU
+// path (modules/video/src/optflow.cpp 4.1.0: FarnebackPolyExp, FarnebackUpdateMatrices,
+// FarnebackUpdateFlow_Blur / _GaussianBlur), every float/double operation rounded where the C++
+// rounds it (the file is built -ffp-contract=off and writes no fmaf), so that the flow field is the
+// CPU path's bit for bit.  Reference call sites: ripcurrents.cpp:215, main.cpp:264, :609, :1119.
+//
+// Why it exists: the fast kernels reorder sums (fp32 FMA chains on DC-removed data, a Kahan fp32
+// solve).  That is within 1e-3 px wherever the 2x2 system is well conditioned, but the
+// sigma = 0.3 window of main.cpp:264 is a near-pointwise solve whose determinant
+// (r4 r5 - r6^2)^2 vanishes on smooth image regions, and there any rounding difference is amplified
+// from scale to scale.  This path removes the rounding differences instead of bounding them.
+// It is also the full-size stand-in for the CPU oracle in the GPU tests (a 4K frame pair
+// takes milliseconds instead of seconds).
+//
+// Everything is staged through HBM, one plain kernel per upstream loop:
+//   I_k (k_pyr_*, already bit-exact)  ->  k_exact_polyexp  ->  R_k
+//   k_exact_flow_init (resize * 1/pyr_scale | zeros)  ->  flow_k
+//   k_exact_matrices  ->  M (5 planes)
+//   Gaussian window: k_exact_gauss_v -> V (float), k_exact_gauss_h_solve -> flow_k
+//   box window:      k_exact_box_vscan -> V (double running column sums, sequential in y like
+//                    upstream's vsum), k_exact_box_hscan_solve (sequential in x) -> flow_k
+
+#include "rc_device.h"
+
+#define RC_EX_TW 64
+#define RC_EX_TH 16
+
+// ------------------------------------------------------------------ FarnebackPolyExp
+// Vertical pass (float) for the tile's columns -n .. TW+n-1 (columns clamped = the replicated
+// row triplets of upstream), then the horizontal pass with upstream's mix: b1 and b4 take the
+// pair sum as a double, every other product is a float product added to a double accumulator.
+__global__ __launch_bounds__(256) void k_exact_polyexp(RcPolyArgs a) {
+    extern __shared__ __align__(16) float rows[];          // [3][TH][TW + 2n]
+    const int n = a.pk.n, CW = RC_EX_TW + 2 * n;
+    const int tid = threadIdx.x, z = blockIdx.z;
+    const int tx0 = blockIdx.x * RC_EX_TW, ty0 = blockIdx.y * RC_EX_TH;
+    const int w = a.w, h = a.h;
+    const int slot = (a.slot0 + z * a.zstep) % a.nslots;
+    const float* I = a.I + (size_t)slot * a.I_slot_stride;
+    float* r0 = rows, *r1 = rows + RC_EX_TH * CW, *r2 = rows + 2 * RC_EX_TH * CW;
+
+    for (int idx = tid; idx < RC_EX_TH * CW; idx += 256) {
+        const int ly = idx / CW, lc = idx - ly * CW;
+        const int y = min(ty0 + ly, h - 1), c = rc_clampi(tx0 - n + lc, 0, w - 1);
+        float t0 = I[(size_t)y * w + c] * a.pk.g[0], t1 = 0.f, t2 = 0.f;
+        for (int k = 1; k <= n; k++) {
+            const float s0 = I[(size_t)max(y - k, 0) * w + c], s1 = I[(size_t)min(y + k, h - 1) * w + c];
+            const float p = s0 + s1;
+            t0 = t0 + a.pk.g[k] * p;
+            t1 = t1 + a.pk.xg[k] * (s1 - s0);
+            t2 = t2 + a.pk.xxg[k] * p;
+        }
+        r0[idx] = t0; r1[idx] = t1; r2[idx] = t2;
+    }
+    __syncthreads();
+    float4* RA = a.RA + (size_t)slot * a.R_slot_stride;
+    float* RB = a.RB + (size_t)slot * a.R_slot_stride;
+    for (int idx = tid; idx < RC_EX_TH * RC_EX_TW; idx += 256) {
+        const int ly = idx / RC_EX_TW, lx = idx - ly * RC_EX_TW;
+        const int x = tx0 + lx, y = ty0 + ly;
+        if (x >= w || y >= h) continue;
+        const float* q0 = r0 + ly * CW + lx + n, *q1 = r1 + ly * CW + lx + n, *q2 = r2 + ly * CW + lx + n;
+        float g0 = a.pk.g[0];
+        double b1 = q0[0] * g0, b2 = 0, b3 = q1[0] * g0, b4 = 0, b5 = q2[0] * g0, b6 = 0;
+        for (int k = 1; k <= n; k++) {
+            const double tg = q0[k] + q0[-k];
+            g0 = a.pk.g[k];
+            b1 += tg * g0;
+            b4 += tg * a.pk.xxg[k];
+            b2 += (q0[k] - q0[-k]) * a.pk.xg[k];
+            b3 += (q1[k] + q1[-k]) * g0;
+            b6 += (q1[k] - q1[-k]) * a.pk.xg[k];
+            b5 += (q2[k] + q2[-k]) * g0;
+        }
+        float4 ra;
+        ra.y = (float)(b2 * a.pk.ig11);
+        ra.x = (float)(b3 * a.pk.ig11);
+        ra.w = (float)(b1 * a.pk.ig03 + b4 * a.pk.ig33);
+        ra.z = (float)(b1 * a.pk.ig03 + b5 * a.pk.ig33);
+        const size_t p = (size_t)y * w + x;
+        RA[p] = ra;
+        RB[p] = (float)(b6 * a.pk.ig55);
+    }
+}
+
+void rc_launch_exact_polyexp(const RcPolyArgs& a, int frames, hipStream_t s) {
+    const size_t lds = sizeof(float) * 3 * RC_EX_TH * (RC_EX_TW + 2 * a.pk.n);
+    dim3 grid((a.w + RC_EX_TW - 1) / RC_EX_TW, (a.h + RC_EX_TH - 1) / RC_EX_TH, frames);
+    hipLaunchKernelGGL(k_exact_polyexp, grid, dim3(256), lds, s, a);
+}
+
+// ------------------------------------------------------------------ calc(): initial flow of a scale
+// zeros at the coarsest scale, else resize(prevFlow, INTER_LINEAR) then *= 1/pyr_scale
+__global__ __launch_bounds__(256) void k_exact_flow_init(RcExactArgs a) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
+    if (x >= a.w || y >= a.h) return;
+    float2 v = make_float2(0.f, 0.f);
+    if (a.fin) {
+        const float2* fin = a.fin + (size_t)z * a.fin_pair_stride;
+        if (a.fin_w == a.w && a.fin_h == a.h) {
+            v = fin[(size_t)y * a.w + x];                  // resize() of an equal size is a copy
+        } else {
+            float ax, ay;
+            const int sx = rc_src_x(x, a.up_scale_x, a.fin_w, ax);
+            const int sx1 = min(sx + 1, a.fin_w - 1);
+            const int sy = rc_src_y(y, a.up_scale_y, ay);
+            const int sy0 = rc_clampi(sy, 0, a.fin_h - 1), sy1 = rc_clampi(sy + 1, 0, a.fin_h - 1);
+            const float2* S0 = fin + (size_t)sy0 * a.fin_w;
+            const float2* S1 = fin + (size_t)sy1 * a.fin_w;
+            const float2 p00 = S0[sx], p01 = S0[sx1], p10 = S1[sx], p11 = S1[sx1];
+            const float a0 = 1.f - ax, a1 = ax, b0 = 1.f - ay, b1 = ay;
+            const float r0x = p00.x * a0 + p01.x * a1, r1x = p10.x * a0 + p11.x * a1;
+            const float r0y = p00.y * a0 + p01.y * a1, r1y = p10.y * a0 + p11.y * a1;
+            v.x = r0x * b0 + r1x * b1;
+            v.y = r0y * b0 + r1y * b1;
+        }
+        v.x = v.x * a.up_mul;
+        v.y = v.y * a.up_mul;
+    }
+    a.flow[(size_t)z * a.n + (size_t)y * a.w + x] = v;
+}
+
+// ------------------------------------------------------------------ FarnebackUpdateMatrices
+__global__ __launch_bounds__(256) void k_exact_matrices(RcExactArgs a) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
+    const int width = a.w, height = a.h;
+    if (x >= width || y >= height) return;
+    const size_t s0 = (size_t)((a.slot0 + z * a.zstep) % a.nslots) * a.n;
+    const size_t s1 = (size_t)((a.slot1 + z * a.zstep) % a.nslots) * a.n;
+    const float4* RA0 = a.RA + s0; const float* RB0 = a.RB + s0;
+    const float4* RA1 = a.RA + s1; const float* RB1 = a.RB + s1;
+    const size_t p0 = (size_t)y * width + x;
+    const float2 d = a.flow[(size_t)z * a.n + p0];
+    const float dx = d.x, dy = d.y;
+    float fx = x + dx, fy = y + dy;
+    const int x1 = rc_cvt_i32_x86(floorf(fx)), y1 = rc_cvt_i32_x86(floorf(fy));
+    float r2, r3, r4, r5, r6;
+    fx -= x1;
+    fy -= y1;
+    const float4 A0 = RA0[p0];
+    const float B0 = RB0[p0];
+    if ((unsigned)x1 < (unsigned)(width - 1) && (unsigned)y1 < (unsigned)(height - 1)) {
+        const size_t p = (size_t)y1 * width + x1;
+        const float4 q00 = RA1[p], q01 = RA1[p + 1], q10 = RA1[p + width], q11 = RA1[p + width + 1];
+        const float e00 = RB1[p], e01 = RB1[p + 1], e10 = RB1[p + width], e11 = RB1[p + width + 1];
+        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        r2 = a00 * q00.x + a01 * q01.x + a10 * q10.x + a11 * q11.x;
+        r3 = a00 * q00.y + a01 * q01.y + a10 * q10.y + a11 * q11.y;
+        r4 = a00 * q00.z + a01 * q01.z + a10 * q10.z + a11 * q11.z;
+        r5 = a00 * q00.w + a01 * q01.w + a10 * q10.w + a11 * q11.w;
+        r6 = a00 * e00 + a01 * e01 + a10 * e10 + a11 * e11;
+        r4 = (A0.z + r4) * 0.5f;
+        r5 = (A0.w + r5) * 0.5f;
+        r6 = (B0 + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = A0.z;
+        r5 = A0.w;
+        r6 = B0 * 0.5f;
+    }
+    r2 = (A0.x - r2) * 0.5f;
+    r3 = (A0.y - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    if ((unsigned)(x - 5) >= (unsigned)(width - 10) || (unsigned)(y - 5) >= (unsigned)(height - 10)) {
+        const float b0 = 0.14f, b2 = 0.4472f;              // border[] = {.14, .14, .4472, .4472, .4472}
+        const int rx = width - x - 1, ry = height - y - 1;
+        const float scale = (x < 5 ? (x < 2 ? b0 : b2) : 1.f) * (x >= width - 5 ? (rx < 2 ? b0 : b2) : 1.f) *
+                            (y < 5 ? (y < 2 ? b0 : b2) : 1.f) * (y >= height - 5 ? (ry < 2 ? b0 : b2) : 1.f);
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
+    float* M = a.M + (size_t)z * 5 * a.n + p0;
+    M[0] = r4 * r4 + r6 * r6;
+    M[a.n] = (r4 + r5) * r6;
+    M[2 * a.n] = r5 * r5 + r6 * r6;
+    M[3 * a.n] = r4 * r2 + r6 * r3;
+    M[4 * a.n] = r6 * r2 + r5 * r3;
+}
+
+__device__ __forceinline__ float2 rc_exact_solve(double g11, double g12, double g22, double h1, double h2) {
+    const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+    float2 f;
+    f.x = (float)((g11 * h2 - g12 * h1) * idet);
+    f.y = (float)((g22 * h1 - g12 * h2) * idet);
+    return f;
+}
+
+// ------------------------------------------------------------------ FarnebackUpdateFlow_GaussianBlur
+// vertical pass: vsum = srow[m] * k[0]; vsum += (srow[m+i] + srow[m-i]) * k[i]   (float)
+__global__ __launch_bounds__(256) void k_exact_gauss_v(RcExactArgs a) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int z = blockIdx.z / 5, c = blockIdx.z - z * 5;
+    if (x >= a.w || y >= a.h) return;
+    const float* M = a.M + ((size_t)z * 5 + c) * a.n;
+    float s0 = M[(size_t)y * a.w + x] * a.win.k[0];
+    for (int i = 1; i <= a.win.m; i++)
+        s0 += (M[(size_t)min(y + i, a.h - 1) * a.w + x] + M[(size_t)max(y - i, 0) * a.w + x]) * a.win.k[i];
+    ((float*)a.V)[((size_t)z * 5 + c) * a.n + (size_t)y * a.w + x] = s0;
+}
+// horizontal pass (replicated columns) + solve in double
+__global__ __launch_bounds__(256) void k_exact_gauss_h_solve(RcExactArgs a) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
+    if (x >= a.w || y >= a.h) return;
+    float hs[5];
+    for (int c = 0; c < 5; c++) {
+        const float* V = (const float*)a.V + ((size_t)z * 5 + c) * a.n + (size_t)y * a.w;
+        float sum = V[x] * a.win.k[0];
+        for (int i = 1; i <= a.win.m; i++) sum += a.win.k[i] * (V[max(x - i, 0)] + V[min(x + i, a.w - 1)]);
+        hs[c] = sum;
+    }
+    const float2 f = rc_exact_solve(hs[0], hs[1], hs[2], hs[3], hs[4]);
+    if (a.out) *(float2*)(a.out + (size_t)z * a.out_pair_stride + (size_t)y * a.out_step + (size_t)x * 8) = f;
+    else a.flow[(size_t)z * a.n + (size_t)y * a.w + x] = f;
+}
+
+// ------------------------------------------------------------------ FarnebackUpdateFlow_Blur
+// upstream's running column sums: double accumulators fed with FLOAT differences of rows, so the
+// rounding of every (srow1 - srow0) is carried down the column; replayed sequentially per column.
+__global__ __launch_bounds__(64) void k_exact_box_vscan(RcExactArgs a) {
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int z = blockIdx.y / 5, c = blockIdx.y - z * 5;
+    if (x >= a.w) return;
+    const int m = a.win.m, h = a.h, w = a.w;
+    const float* M = a.M + ((size_t)z * 5 + c) * a.n + x;
+    double* V = (double*)a.V + ((size_t)z * 5 + c) * a.n + x;
+    double vsum = M[0] * (m + 2);                          // float product
+    for (int y = 1; y < m; y++) vsum += M[(size_t)min(y, h - 1) * w];
+    for (int y = 0; y < h; y++) {
+        const float s0 = M[(size_t)max(y - m - 1, 0) * w], s1 = M[(size_t)min(y + m, h - 1) * w];
+        vsum += s1 - s0;
+        V[(size_t)y * w] = vsum;
+    }
+}
+// one thread per row: the running row sums (double), scale, solve
+__global__ __launch_bounds__(64) void k_exact_box_hscan_solve(RcExactArgs a) {
+    const int y = blockIdx.x * 64 + threadIdx.x, z = blockIdx.y;
+    if (y >= a.h) return;
+    const int m = a.win.m, w = a.w;
+    const double* V[5];
+    double g[5];
+    for (int c = 0; c < 5; c++) {
+        V[c] = (const double*)a.V + ((size_t)z * 5 + c) * a.n + (size_t)y * w;
+        g[c] = V[c][0] * (m + 2);
+        for (int x = 1; x < m; x++) g[c] += V[c][min(x, w - 1)];
+    }
+    const double scale = a.win.box_scale;
+    for (int x = 0; x < w; x++) {
+        const int xa = min(x + m, w - 1), xb = max(x - m - 1, 0);
+        for (int c = 0; c < 5; c++) g[c] += V[c][xa] - V[c][xb];
+        const float2 f = rc_exact_solve(g[0] * scale, g[1] * scale, g[2] * scale, g[3] * scale, g[4] * scale);
+        if (a.out) *(float2*)(a.out + (size_t)z * a.out_pair_stride + (size_t)y * a.out_step + (size_t)x * 8) = f;
+        else a.flow[(size_t)z * a.n + (size_t)y * w + x] = f;
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+void rc_launch_exact_flow_init(const RcExactArgs& a, int pairs, hipStream_t s) {
+    hipLaunchKernelGGL(k_exact_flow_init, dim3((a.w + 63) / 64, (a.h + 3) / 4, pairs), dim3(256), 0, s, a);
+}
+void rc_launch_exact_matrices(const RcExactArgs& a, int pairs, hipStream_t s) {
+    hipLaunchKernelGGL(k_exact_matrices, dim3((a.w + 63) / 64, (a.h + 3) / 4, pairs), dim3(256), 0, s, a);
+}
+void rc_launch_exact_window_solve(const RcExactArgs& a, int pairs, hipStream_t s) {
+    if (a.win.gaussian) {
+        hipLaunchKernelGGL(k_exact_gauss_v, dim3((a.w + 63) / 64, (a.h + 3) / 4, pairs * 5), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_exact_gauss_h_solve, dim3((a.w + 63) / 64, (a.h + 3) / 4, pairs), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(k_exact_box_vscan, dim3((a.w + 63) / 64, pairs * 5), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_exact_box_hscan_solve, dim3((a.h + 63) / 64, pairs), dim3(64), 0, s, a);
+    }
+}

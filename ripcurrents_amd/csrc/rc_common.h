@@ -142,6 +142,30 @@ struct RcIterArgs {
     RcWindow win;
 };
 
+// Option "exact" (exact_kernels.hip): one scale of the upstream CPU operation order, staged through HBM.
+struct RcExactArgs {
+    const float4* RA;         // R slot base of this scale
+    const float* RB;
+    size_t n;                 // pixels of the scale (= R slot stride, plane stride of M / V)
+    int slot0, slot1, nslots, zstep;
+    int w, h;
+    const float2* fin;        // flow of the coarser scale (null at the coarsest)
+    size_t fin_pair_stride;
+    int fin_w, fin_h;
+    double up_scale_x, up_scale_y;
+    float up_mul;
+    float2* flow;             // [pairs][h][w]
+    float* M;                 // [pairs][5][h][w]
+    void* V;                  // [pairs][5][h][w]: float (Gaussian window) / double (box window)
+    char* out;                // last iteration of scale 0: the caller's buffer (else null -> flow)
+    size_t out_step, out_pair_stride;
+    RcWindow win;
+};
+void rc_launch_exact_polyexp(const RcPolyArgs& a, int frames, hipStream_t s);
+void rc_launch_exact_flow_init(const RcExactArgs& a, int pairs, hipStream_t s);
+void rc_launch_exact_matrices(const RcExactArgs& a, int pairs, hipStream_t s);
+void rc_launch_exact_window_solve(const RcExactArgs& a, int pairs, hipStream_t s);
+
 // Raises a kernel's dynamic-LDS limit once per (call site, device): the attribute is per device, and a
 // process may hold contexts on several devices.
 #define RC_MAX_DEVICES 64

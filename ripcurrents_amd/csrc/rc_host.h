@@ -22,6 +22,7 @@ struct RcPlan {
     RcWindow win;
     int nslots = 0, chunk = 0;
     int exact_taps = 0;
+    int exact = 0;
 };
 
 // Device-resident analysis state of one stream slot (ripcurrents.cpp:133-176).
@@ -51,6 +52,7 @@ struct RcSlot {
     RcBuf I[RC_MAX_LEVELS], RA[RC_MAX_LEVELS], RB[RC_MAX_LEVELS];
     RcBuf FA[RC_MAX_LEVELS], FB[RC_MAX_LEVELS];
     RcBuf stage_u8, stage_flow, stage_f32[4];
+    RcBuf exM, exV;            // option "exact": matrix planes and window column sums
     RcBuf lk;                  // sparse PyrLK pyramids + derivatives (lk_kernels.hip)
     RcBuf area_tab;            // INTER_AREA decimation tables
     int primed = 0, cur_slot = 0;
@@ -75,6 +77,7 @@ struct rc_ctx {
     RcSlot* slots = nullptr;
     int chunk = 32;
     int exact_taps = 0;
+    int exact = -1;            // option "exact": upstream's CPU operation order (exact_kernels.hip); -1 = where the fast path cannot hold the tolerance
     int fuse_iters = 1;
     int xcd_remap = 1;
     int poly_tile_h = 32;

@@ -180,6 +180,7 @@ static void slot_free(RcSlot& s) {
     }
     rc_batch_graph_drop(s);
     rc_buf_free(s.stage_u8); rc_buf_free(s.stage_flow); rc_buf_free(s.lk); rc_buf_free(s.area_tab);
+    rc_buf_free(s.exM); rc_buf_free(s.exV);
     for (auto& b : s.stage_f32) rc_buf_free(b);
     rc_buf_free(s.an.hist); rc_buf_free(s.an.hist_part); rc_buf_free(s.an.thr); rc_buf_free(s.an.acc);
     rc_buf_free(s.an.pt); rc_buf_free(s.an.dist); rc_buf_free(s.an.scratch); rc_buf_free(s.an.jet);
@@ -237,6 +238,9 @@ extern "C" int rcflow_set_option(rc_ctx* ctx, const char* name, int value) {
         ctx->chunk = value;
     } else if (!strcmp(name, "exact_taps")) {
         ctx->exact_taps = value ? 1 : 0;
+    } else if (!strcmp(name, "exact")) {
+        if (value < -1 || value > 1) return RC_EINVAL;
+        ctx->exact = value;
     } else if (!strcmp(name, "fuse_iters")) {
         ctx->fuse_iters = value ? 1 : 0;
     } else if (!strcmp(name, "xcd_remap")) {
@@ -356,28 +360,37 @@ static int host_prepare_poly(int n, double sigma, int exact_taps, RcPolyK& pk) {
     G[2][2] = G[0][3] = G[0][4] = G[3][0] = G[4][0] = G[1][1];
     G[4][4] = G[3][3];
     G[3][4] = G[4][3] = G[5][5];
-    // Cholesky G = L L^T, then invG = L^-T L^-1
-    double L[6][6] = {{0}}, Li[6][6] = {{0}}, inv[6][6] = {{0}};
+    // invG = G.inv(DECOMP_CHOLESKY): cv::invert -> hal::Cholesky64f on the identity (core/src/matrix_decomp.cpp
+    // CholImpl<double>: 1/sqrt(pivot) on the diagonal, forward then backward substitution), restated
+    // operation for operation so that the four scalars carry upstream's bits.
+    double L[6][6], inv[6][6];
     for (int i = 0; i < 6; i++)
-        for (int j = 0; j <= i; j++) {
-            double v = G[i][j];
-            for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k];
-            if (i == j) {
-                if (!(v > 0)) return RC_EINVAL;
-                L[i][i] = sqrt(v);
-            } else {
-                L[i][j] = v / L[j][j];
-            }
+        for (int j = 0; j < 6; j++) { L[i][j] = G[i][j]; inv[i][j] = i == j ? 1. : 0.; }
+    for (int i = 0; i < 6; i++) {
+        double v;
+        int j, k;
+        for (j = 0; j < i; j++) {
+            v = L[i][j];
+            for (k = 0; k < j; k++) v -= L[i][k] * L[j][k];
+            L[i][j] = v * L[j][j];
         }
-    for (int c = 0; c < 6; c++)
-        for (int i = 0; i < 6; i++) {
-            double v = i == c ? 1. : 0.;
-            for (int k = 0; k < i; k++) v -= L[i][k] * Li[k][c];
-            Li[i][c] = v / L[i][i];
-        }
+        v = L[i][i];
+        for (k = 0; k < j; k++) { double t = L[i][k]; v -= t * t; }
+        if (!(v >= DBL_EPSILON)) return RC_EINVAL;
+        L[i][i] = 1. / sqrt(v);
+    }
     for (int i = 0; i < 6; i++)
-        for (int j = 0; j < 6; j++)
-            for (int k = 0; k < 6; k++) inv[i][j] += Li[k][i] * Li[k][j];
+        for (int j = 0; j < 6; j++) {
+            double v = inv[i][j];
+            for (int k = 0; k < i; k++) v -= L[i][k] * inv[k][j];
+            inv[i][j] = v * L[i][i];
+        }
+    for (int i = 5; i >= 0; i--)
+        for (int j = 0; j < 6; j++) {
+            double v = inv[i][j];
+            for (int k = 5; k > i; k--) v -= L[k][i] * inv[k][j];
+            inv[i][j] = v * L[i][i];
+        }
     pk.ig11 = inv[1][1];
     pk.ig03 = inv[0][3];
     pk.ig33 = inv[3][3];
@@ -478,14 +491,30 @@ static int ensure_plan(rc_ctx* ctx, RcSlot& s, int w, int h, const rc_farneback_
         return RC_ESIZE;
     }
     RcPlan& pl = s.plan;
-    if (pl.valid && pl.w == w && pl.h == h && !memcmp(&pl.prm, p, sizeof(*p)) && pl.chunk == chunk &&
-        pl.nslots == nslots && pl.exact_taps == ctx->exact_taps)
+    // field by field: the struct has tail padding that a caller's brace-initialised copy leaves indeterminate
+    const rc_farneback_params& q = pl.prm;
+    const bool same_prm = q.pyr_scale == p->pyr_scale && q.levels == p->levels && q.winsize == p->winsize &&
+                          q.iterations == p->iterations && q.poly_n == p->poly_n && q.poly_sigma == p->poly_sigma &&
+                          q.flags == p->flags;
+    // Option "exact" = -1 (default): upstream's operation order wherever the window is a near-pointwise
+    // solve (Gaussian winsize < 7: sigma = 0.3 m <= 0.6, the centre tap carries >= half of the weight;
+    // winsize 1) -- there the 2x2 determinant vanishes on smooth regions and the fast kernels' rounding
+    // differences are amplified beyond any tolerance (main.cpp:264).
+    const int exact = ctx->exact >= 0 ? ctx->exact
+                                      : (p->winsize / 2 == 0 || ((p->flags & RC_FARNEBACK_GAUSSIAN) && p->winsize / 2 <= 2));
+    if (pl.valid && pl.w == w && pl.h == h && same_prm && pl.chunk == chunk &&
+        pl.nslots == nslots && pl.exact_taps == ctx->exact_taps && pl.exact == exact)
         return RC_OK;
     rc_batch_graph_drop(s);
     RC_HIP(hipStreamSynchronize(s.cur));
     pl.valid = false;
-    pl.w = w; pl.h = h; pl.prm = *p; pl.chunk = chunk; pl.nslots = nslots;
+    pl.w = w; pl.h = h; pl.chunk = chunk; pl.nslots = nslots;
+    memset(&pl.prm, 0, sizeof(pl.prm));
+    pl.prm.pyr_scale = p->pyr_scale; pl.prm.levels = p->levels; pl.prm.winsize = p->winsize;
+    pl.prm.iterations = p->iterations; pl.prm.poly_n = p->poly_n; pl.prm.poly_sigma = p->poly_sigma;
+    pl.prm.flags = p->flags;
     pl.exact_taps = ctx->exact_taps;
+    pl.exact = exact;
     int L = crop_levels(w, h, p->pyr_scale, p->levels);
     pl.nlev = L + 1;
     size_t kern_total = 0;
@@ -496,7 +525,7 @@ static int ensure_plan(rc_ctx* ctx, RcSlot& s, int w, int h, const rc_farneback_
         pl.kern_off[k] = kern_total;
         kern_total += (pl.lv[k].ksize + 3) & ~3;
     }
-    int rc = host_prepare_poly(p->poly_n, p->poly_sigma, ctx->exact_taps, pl.pk);
+    int rc = host_prepare_poly(p->poly_n, p->poly_sigma, ctx->exact_taps || exact, pl.pk);
     if (rc) { rc_set_error("polynomial-expansion moment matrix is not positive definite"); return rc; }
     host_window(p->winsize, p->flags, pl.win);
 
@@ -506,7 +535,7 @@ static int ensure_plan(rc_ctx* ctx, RcSlot& s, int w, int h, const rc_farneback_
     RC_HIP(hipMemcpy(s.kern.p, kh.data(), kern_total * sizeof(float), hipMemcpyHostToDevice));
     for (int k = 0; k <= L; k++) {
         size_t n = (size_t)pl.lv[k].w * pl.lv[k].h;
-        if (k > 0 && (rc = rc_buf_ensure(s.I[k], n * pl.nslots * sizeof(float)))) return rc;
+        if ((k > 0 || exact) && (rc = rc_buf_ensure(s.I[k], n * pl.nslots * sizeof(float)))) return rc;
         if ((rc = rc_buf_ensure(s.RA[k], n * pl.nslots * sizeof(float4)))) return rc;
         if ((rc = rc_buf_ensure(s.RB[k], n * pl.nslots * sizeof(float)))) return rc;
         if ((rc = rc_buf_ensure(s.FA[k], n * chunk * sizeof(float2)))) return rc;
@@ -533,7 +562,7 @@ static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t fr
         q.RA = (float4*)s.RA[k].p; q.RB = (float*)s.RB[k].p; q.R_slot_stride = n;
         q.slot0 = dslot0; q.nslots = pl.nslots; q.zstep = zstep; q.w = L.w; q.h = L.h; q.pk = pl.pk;
         q.tile_h = ctx->poly_tile_h; q.no_fast_u8 = (ctx->ablate & RC_ABL_NO_FAST_U8) != 0; q.valu_vertical = !ctx->poly_mfma;
-        if (k == 0) {
+        if (k == 0 && !pl.exact) {
             // scale 0: pyramid (3x3 blur, identity resize) fused into the expansion
             q.src8 = d_src; q.src8_step = step; q.src8_frame_stride = frame_stride;
             continue;
@@ -551,6 +580,18 @@ static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t fr
         p.direct = (ctx->ablate & RC_ABL_PYR_STAGED) != 0;
     }
     auto npx = [&](int k) { return (double)pl.lv[k].w * pl.lv[k].h; };
+    if (pl.exact) {
+        // option "exact": every scale (0 included) through the bit-exact pyramid kernels, then the
+        // expansion in upstream's operation order
+        for (int k = 0; k < pl.nlev; k++) {
+            { RcProfScope ps(ctx, s.cur, RC_K_PYR, k, (double)count * (npx(0) + 4. * npx(k)));
+              rc_launch_pyr(pa[k], count, pl.lv[k].pyr_lds, s.cur); }
+            RcProfScope ps(ctx, s.cur, RC_K_POLY, k, (double)count * 24. * npx(k));
+            rc_launch_exact_polyexp(qa[k], count, s.cur);
+        }
+        RC_HIP(hipGetLastError());
+        return RC_OK;
+    }
     // A frame or two per call (the frame-at-a-time loop, two-image calls): the scales' grids are each
     // smaller than the GPU and independent of one another, so scales 1 + 2 of the pyramid share one launch
     // and the expansions of scales 0..2 another (block-index dispatch; same tile code, same bits).
@@ -607,9 +648,55 @@ static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t fr
     return RC_OK;
 }
 
+// Option "exact": the level driver over exact_kernels.hip (M and the window's column sums in HBM).
+static int compute_flows_exact(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_out, size_t out_pair_stride,
+                               size_t out_step, int slot1, int zstep) {
+    RcPlan& pl = s.plan;
+    const int iters = pl.prm.iterations;
+    const size_t n0 = (size_t)pl.lv[0].w * pl.lv[0].h;
+    int rc;
+    if ((rc = rc_buf_ensure(s.exM, n0 * 5 * pairs * sizeof(float)))) return rc;
+    if ((rc = rc_buf_ensure(s.exV, n0 * 5 * pairs * (pl.win.gaussian ? sizeof(float) : sizeof(double))))) return rc;
+    const float2* coarse = nullptr;
+    int cw = 0, ch = 0;
+    for (int k = pl.nlev - 1; k >= 0; k--) {
+        const RcLevel& L = pl.lv[k];
+        RcExactArgs a;
+        memset(&a, 0, sizeof(a));
+        a.RA = (const float4*)s.RA[k].p; a.RB = (const float*)s.RB[k].p; a.n = (size_t)L.w * L.h;
+        a.slot0 = slot0; a.slot1 = slot1 >= 0 ? slot1 : (slot0 + 1) % pl.nslots; a.nslots = pl.nslots; a.zstep = zstep;
+        a.w = L.w; a.h = L.h; a.win = pl.win;
+        a.flow = (float2*)s.FA[k].p; a.M = (float*)s.exM.p; a.V = s.exV.p;
+        if (coarse) {
+            a.fin = coarse; a.fin_pair_stride = (size_t)cw * ch; a.fin_w = cw; a.fin_h = ch;
+            a.up_scale_x = 1. / ((double)L.w / cw); a.up_scale_y = 1. / ((double)L.h / ch);
+            a.up_mul = (float)(1. / pl.prm.pyr_scale);
+        }
+        const double nb = (double)pairs * a.n;
+        { RcProfScope ps(ctx, s.cur, RC_K_ITER, k, 8. * nb + (coarse ? 8. * pairs * cw * ch : 0.));
+          rc_launch_exact_flow_init(a, pairs, s.cur); }
+        if (iters > 0) { RcProfScope ps(ctx, s.cur, RC_K_ITER, k, 68. * nb); rc_launch_exact_matrices(a, pairs, s.cur); }
+        for (int i = 0; i < iters; i++) {
+            if (k == 0 && i == iters - 1) { a.out = (char*)d_out; a.out_step = out_step; a.out_pair_stride = out_pair_stride; }
+            { RcProfScope ps(ctx, s.cur, RC_K_ITER, k, (pl.win.gaussian ? 68. : 108.) * nb);
+              rc_launch_exact_window_solve(a, pairs, s.cur); }
+            if (i < iters - 1) { RcProfScope ps(ctx, s.cur, RC_K_ITER, k, 68. * nb); rc_launch_exact_matrices(a, pairs, s.cur); }
+        }
+        if (k == 0 && iters == 0)
+            for (int z = 0; z < pairs; z++)
+                RC_HIP(hipMemcpy2DAsync((char*)d_out + (size_t)z * out_pair_stride, out_step, a.flow + (size_t)z * a.n,
+                                        (size_t)L.w * 8, (size_t)L.w * 8, (size_t)L.h, hipMemcpyDeviceToDevice, s.cur));
+        coarse = a.flow;
+        cw = L.w; ch = L.h;
+    }
+    RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
 // Coarse-to-fine flow for `pairs` frame pairs whose expansions sit in slots slot0+z, slot0+z+1.
 static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_out, size_t out_pair_stride,
                          size_t out_step, int slot1 = -1, int zstep = 1) {
+    if (s.plan.exact) return compute_flows_exact(ctx, s, pairs, slot0, d_out, out_pair_stride, out_step, slot1, zstep);
     RcPlan& pl = s.plan;
     const int iters = pl.prm.iterations;
     const float2* coarse = nullptr;
@@ -1018,8 +1105,9 @@ extern "C" int rcflow_stage_polyexp_dev(rc_ctx* ctx, int stream, const float* d_
     qa.I = d_I; qa.I_slot_stride = 0;
     qa.RA = (float4*)s->stage_f32[0].p; qa.RB = (float*)s->stage_f32[1].p; qa.R_slot_stride = 0;
     qa.slot0 = 0; qa.nslots = 1; qa.zstep = 1; qa.w = w; qa.h = h; qa.tile_h = ctx->poly_tile_h; qa.valu_vertical = !ctx->poly_mfma;
-    if ((rc = host_prepare_poly(poly_n, poly_sigma, ctx->exact_taps, qa.pk))) return rc;
-    rc_launch_polyexp(qa, 1, s->cur);
+    if ((rc = host_prepare_poly(poly_n, poly_sigma, ctx->exact_taps || ctx->exact == 1, qa.pk))) return rc;
+    if (ctx->exact == 1) rc_launch_exact_polyexp(qa, 1, s->cur);
+    else rc_launch_polyexp(qa, 1, s->cur);
     rc_launch_unpack_R5(qa.RA, qa.RB, d_R5, (int)n, s->cur);
     RC_HIP(hipGetLastError());
     return RC_OK;
@@ -1043,6 +1131,22 @@ extern "C" int rcflow_stage_flow_iter_dev(rc_ctx* ctx, int stream, const float* 
     rc_launch_pack_R5(d_R1, RA + n, RB + n, (int)n, s->cur);
     RcWindow win;
     host_window(winsize, flags, win);
+    if (ctx->exact == 1) {
+        if ((rc = rc_buf_ensure(s->exM, n * 5 * sizeof(float)))) return rc;
+        if ((rc = rc_buf_ensure(s->exV, n * 5 * sizeof(double)))) return rc;
+        if ((rc = rc_buf_ensure(s->stage_f32[2], n * sizeof(float2)))) return rc;
+        RcExactArgs e;
+        memset(&e, 0, sizeof(e));
+        e.RA = RA; e.RB = RB; e.n = n; e.slot0 = 0; e.slot1 = 1; e.nslots = 2; e.zstep = 1; e.w = w; e.h = h; e.win = win;
+        e.flow = (float2*)s->stage_f32[2].p; e.M = (float*)s->exM.p; e.V = s->exV.p;
+        if (d_flow_in) RC_HIP(hipMemcpyAsync(e.flow, d_flow_in, n * sizeof(float2), hipMemcpyDeviceToDevice, s->cur));
+        else RC_HIP(hipMemsetAsync(e.flow, 0, n * sizeof(float2), s->cur));
+        rc_launch_exact_matrices(e, 1, s->cur);
+        e.out = (char*)d_flow_out; e.out_step = (size_t)w * 8; e.out_pair_stride = n * 8;
+        rc_launch_exact_window_solve(e, 1, s->cur);
+        RC_HIP(hipGetLastError());
+        return RC_OK;
+    }
     RcIterArgs a;
     memset(&a, 0, sizeof(a));
     a.RA = RA; a.RB = RB; a.R_slot_stride = n; a.slot0 = 0; a.slot1 = 1; a.nslots = 2; a.zstep = 1;
