@@ -12,9 +12,10 @@ model) and `--pairs` flow fields are produced, then the segment's flow histogram
 accumulated (and, for N>1, all-reduced over RCCL: 1887 int32).  Each rank owns an
 independent segment (seed 1234+rank): weak scaling, no data-path collective.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP events on the kernel's
-stream inside the timed region) and, at N=1, `cpu_baseline` (the CPU oracle timed on this
-host on a bounded sample of the same clip).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: compulsory bytes of the launch as
+built / its mean duration from HIP events on the kernel's stream inside the timed region / 8 TB/s),
+`pipeline` (the whole step against the same peak) and, at N=1, `cpu_baseline` (the CPU oracle timed
+on this host on a bounded sample of the same clip).
 """
 import argparse
 import json
@@ -46,18 +47,23 @@ def survey_model_bytes_per_frame(w, h, levels, iters):
     return total
 
 
+PMC_FILE = "profiles/r02_pmc_traffic.json"
+
+
 def pmc_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_traffic.json; PMC cannot be collected inside this process).  Null when
-    the launch shape differs from the profiled one."""
+    """HBM bytes per launch of `kernel` and per flow field of the whole step, from the committed
+    rocprofv3 --pmc passes (PMC_FILE, collected by scripts/pmc_multi.sh on the same bench command in
+    separate runs -- counters cannot be collected inside this process).  None when the launch shape
+    differs from the profiled one or the file is absent."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, PMC_FILE)))
         chunk = args.chunk or 32
         if min(chunk, args.pairs) != d["pairs_per_launch"] or args.gaussian:
-            return None
-        return d["kernels"][kernel]["traffic_bytes_per_launch"]
+            return None, None, None
+        src = "%s (%s; commit %s)" % (PMC_FILE, d.get("collected", "separate --pmc passes"), d.get("commit", "?"))
+        return d["kernels"][kernel]["traffic_bytes_per_launch"], d.get("pipeline_bytes_per_field"), src
     except Exception:
-        return None
+        return None, None, None
 
 
 def main():
@@ -65,6 +71,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup-seconds", type=float, default=1.0,
+                    help="untimed steps continue after --warmup until this much time has passed (clocks and "
+                         "caches at steady state however small --warmup is); 0 disables")
     ap.add_argument("--pairs", type=int, default=32, help="frame pairs (flow fields) per step")
     ap.add_argument("--chunk", type=int, default=0, help="pairs per launch (0 = library default)")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -135,6 +144,9 @@ def main():
     nstep = [0]
 
     def step():
+        # a step is one segment of `pairs` frames: its histogram starts from zero (int32 counters:
+        # 32 x 2.07 M counts per step; cumulative over the run they would wrap after ~32 steps)
+        ctx.histogram_reset()
         if args.clip_per_step:
             ctx.farneback_clip(frames, flows, **params)
         else:
@@ -156,8 +168,22 @@ def main():
         else:
             ctx.thresholds()
 
+    t_w = time.perf_counter()
+    warm_run = 0
     for _ in range(args.warmup):
         step()
+        warm_run += 1
+    # time-based floor: every rank runs the same number of extra untimed steps (rank 0's clock decides)
+    while args.warmup_seconds > 0:
+        torch.cuda.synchronize()
+        more = torch.tensor([1 if time.perf_counter() - t_w < args.warmup_seconds else 0], device=dev)
+        if world > 1:
+            dist.broadcast(more, 0)
+        if not int(more.item()):
+            break
+        for _ in range(4):
+            step()
+            warm_run += 1
     finish_pending()
     torch.cuda.synchronize()
     events = not args.no_kernel_events
@@ -206,7 +232,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "C2 1920x1080 synthetic surf clip, 3 pyramid scales (levels=2), "
                                    "winsize 3, iters 2, poly_n 15, sigma 1.2, flags %d; %d flow fields per "
-                                   "step per GPU, %s; + flow histogram"
+                                   "step per GPU, %s; + the flow histogram and thresholds of the step's fields (counters reset per step)"
                                    % (params["flags"], args.pairs,
                                       "an independent clip of %d frames per step (%d expansions)" % (args.pairs + 1, args.pairs + 1)
                                       if args.clip_per_step else
@@ -214,35 +240,49 @@ def main():
                                       "expanded once; the clip is played forwards and backwards)" % args.pairs),
                        "pairs_per_step": args.pairs, "segments": world,
                        "collective": ("all_reduce int32[1887] per step" + ("" if args.sync_collective else ", overlapped with the next step")) if world > 1 else "none"},
+            "warmup_steps_run": warm_run,
             "survey_model": {"bytes_per_frame": model_b,
-                             "frac_of_8TBs": round(fps / world * model_b / (HBM_PEAK_GBS * 1e9), 4)},
+                             "frac_of_8TBs": round(fps / world * model_b / (HBM_PEAK_GBS * 1e9), 4),
+                             "note": "SURVEY.md 8(d) UNFUSED byte model x fps / 8 TB/s: the pipeline as built never "
+                                     "materialises M and fuses two iterations, so it moves far fewer bytes than this "
+                                     "model -- a throughput yardstick (70 % = 10 278 frames/s), not a roofline fraction"},
         }
         if prof:
             tot = sum(p["total_ms"] for p in prof)
             dom = max(prof, key=lambda p: p["total_ms"])
             secs = dom["total_ms"] * 1e-3
-            ach = dom["model_bytes"] / secs / 1e9          # SURVEY 8(d) algorithmic bytes (the contract's figure)
-            own = dom["alg_bytes"] / secs / 1e9            # what this kernel has to move at minimum
-            out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(ach, 1),
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                               "traffic": pmc_traffic(dom["kernel"], args),
+            own = dom["alg_bytes"] / secs / 1e9            # compulsory bytes: inputs once + outputs once, as built
+            traffic, pipe_bytes, src = pmc_traffic(dom["kernel"], args)
+            out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(own, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(own / HBM_PEAK_GBS, 4),
+                               "traffic": traffic, "traffic_source": src,
                                "avg_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
-                               "alg_bytes_per_launch": dom["model_bytes"] / dom["launches"],
-                               "alg_bytes_def": "SURVEY.md 8(d) bytes of the stages the launch stands for "
-                                                "(init matrices + iteration + last iteration for the fused pair)",
-                               "compulsory": {"bytes_per_launch": dom["alg_bytes"] / dom["launches"],
-                                              "achieved": round(own, 1), "frac": round(own / HBM_PEAK_GBS, 4),
-                                              "note": "inputs once + outputs once of the kernel as built "
-                                                      "(M never materialised, two iterations per launch)"},
+                               "alg_bytes_per_launch": dom["alg_bytes"] / dom["launches"],
+                               "alg_bytes_def": "compulsory bytes of the launch as built: R0 20 + R1 20 + coarse flow 2 + "
+                                                "flow out 8 = 50 B per pixel x 2 073 600 px x pairs per launch "
+                                                "(M never exists in HBM, two iterations per launch)",
+                               "frac_of_traffic": round(traffic / secs * dom["launches"] / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                               "survey_model_equivalent": {"bytes_per_launch": dom["model_bytes"] / dom["launches"],
+                                                           "GBs": round(dom["model_bytes"] / secs / 1e9, 1),
+                                                           "note": "SURVEY 8(d) bytes of the stages this launch replaces; "
+                                                                   "exceeds the peak because those bytes are never moved"},
                                "share_of_gpu_time": round(dom["total_ms"] / tot, 3)}
+            # whole step: compulsory bytes of every launch of a sampled step / wall time of a step
+            step_bytes = sum(p["alg_bytes"] for p in prof) / len(range(0, args.steps, args.event_every))
+            out["pipeline"] = {"compulsory_bytes_per_step": step_bytes,
+                               "frac": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                               "measured_bytes_per_field": pipe_bytes,
+                               "frac_measured": round(pipe_bytes * fps / world / 1e9 / HBM_PEAK_GBS, 4) if pipe_bytes else None,
+                               "note": "whole step (expansions + flow + histogram) against 8 TB/s: compulsory bytes as "
+                                       "built, and FETCH/WRITE_SIZE bytes from the committed --pmc passes"}
             if roof:
                 # also against the roof this device actually reaches (streaming kernels, 1 GiB)
                 out["roofline"]["peak_measured"] = {k: round(v, 1) for k, v in roof.items()}
-                out["roofline"]["compulsory"]["frac_of_measured_read"] = round(own / roof["read"], 4)
+                out["roofline"]["frac_of_measured_read"] = round(own / roof["read"], 4)
             out["kernels"] = [{"kernel": p["kernel"], "launches": p["launches"],
                                "avg_us": round(1e3 * p["total_ms"] / p["launches"], 2),
-                               "GBs_model": round(p["model_bytes"] / (p["total_ms"] * 1e-3) / 1e9, 1),
-                               "GBs_compulsory": round(p["alg_bytes"] / (p["total_ms"] * 1e-3) / 1e9, 1)} for p in prof]
+                               "GBs_compulsory": round(p["alg_bytes"] / (p["total_ms"] * 1e-3) / 1e9, 1),
+                               "frac": round(p["alg_bytes"] / (p["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for p in prof]
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle   # checker timed as the CPU baseline, never the product
             host = frames[:args.cpu_pairs + 1].cpu().numpy()

@@ -177,6 +177,10 @@ int rcflow_analysis_reset(rc_ctx* ctx, int stream, int w, int h);
  * Adds this flow field's counts to the slot's cumulative histogram. */
 int rcflow_histogram_dev(rc_ctx* ctx, int stream, const float* d_flow_xy, size_t flow_step,
                          int w, int h);
+/* The counters are int32 like the reference's (`int hist[50]`, ripcurrents.cpp:147-150, which wrap after
+ * 2^31 / (w*h) frames): a call that could carry histsum past INT32_MAX returns RC_ESTATE and counts nothing;
+ * rcflow_histogram_reset_dev starts a new segment (asynchronous zero of the counters only). */
+int rcflow_histogram_reset_dev(rc_ctx* ctx, int stream);
 /* The same for `count` resident flow fields in one launch (a segment's flows). */
 int rcflow_histogram_clip_dev(rc_ctx* ctx, int stream, const float* d_flows_xy,
                               size_t flow_frame_stride, size_t flow_step, int count, int w, int h);

@@ -63,6 +63,7 @@ SIGNATURES = {
     "rcflow_thresholds_words_dev": [_vp, _i, _vp],
     "rcflow_histogram_read": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rcflow_histogram_write": [_vp, _i, _vp],
+    "rcflow_histogram_reset_dev": [_vp, _i],
     "rcflow_histogram_device_ptr": [_vp, _i, C.POINTER(_vp)],
     "rcflow_classify_accumulate_dev": [_vp, _i, _vp, _sz, _i, _i, _i, _f, _f, _vp, _sz, _vp, _sz,
                                        _vp, _sz, _vp, _sz],

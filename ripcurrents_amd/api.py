@@ -335,6 +335,11 @@ class Context:
         self._bind(stream)
         check(self._lib.rcflow_histogram_write(self._h, stream, words.ctypes.data))
 
+    def histogram_reset(self, stream=0):
+        """Starts a new segment: zeroes the cumulative counters (asynchronous, on the slot's stream)."""
+        self._bind(stream)
+        check(self._lib.rcflow_histogram_reset_dev(self._h, stream))
+
     def create_flow_accumulate(self, current, framecount, MID=0.5, LOWER=0.2, want=("polar", "waterclass",
                                "out", "outmask"), stream=0):
         """create_flow + create_accumulationbuffer (ripcurrents_module.cpp:153-212) in one pass.

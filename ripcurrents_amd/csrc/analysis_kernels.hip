@@ -652,6 +652,7 @@ static int analysis_ensure(rc_ctx* ctx, RcSlot& s, int w, int h, bool reset) {
     if ((rc = rc_buf_ensure(an.dist, n * sizeof(float)))) return rc;
     if ((rc = rc_buf_ensure(an.scratch, (4 * 2048 + 8) * sizeof(double)))) return rc;
     an.w = w; an.h = h;
+    an.hist_added = 0;
     RC_HIP(hipMemsetAsync(an.hist.p, 0, RC_HIST_WORDS * sizeof(int), s.cur));
     RC_HIP(hipMemsetAsync(an.hist_part.p, 0, RC_HIST_COPIES * RC_HIST_DIRECTIONS * RC_HIST_BINS * sizeof(int), s.cur));
     RC_HIP(hipMemsetAsync(an.acc.p, 0, n * sizeof(float), s.cur));
@@ -691,6 +692,15 @@ extern "C" int rcflow_histogram_clip_dev(rc_ctx* ctx, int stream, const float* d
     if ((long long)w * h > 0x3fffffffll) { rc_set_error("frame too large for the histogram kernel's 32-bit item index"); return RC_ESIZE; }
     RC_HIP(hipSetDevice(ctx->device));
     if ((rc = analysis_ensure(ctx, *s, w, h, false))) return rc;
+    // The counters are the reference's `int` (ripcurrents.cpp:147-150, never reset there: they wrap after
+    // 2^31 / (w h) frames, about four minutes of 640x480 video).  Every pixel adds at most one count, so the
+    // pixels added since the last reset bound histsum: refuse the call that could wrap it.
+    if (s->an.hist_added + (long long)w * h * count > 0x7fffffffll) {
+        rc_set_error("flow histogram would exceed its int32 counters (%lld pixels counted since the last reset): "
+                     "start a new segment with rcflow_histogram_reset_dev", s->an.hist_added);
+        return RC_ESTATE;
+    }
+    s->an.hist_added += (long long)w * h * count;
     {
         RcProfScope ps(ctx, s->cur, RC_K_HIST, 0, 8. * w * h * count);
         long long per_frame = ((long long)(w + 1) / 2) * h;
@@ -769,6 +779,19 @@ extern "C" int rcflow_histogram_write(rc_ctx* ctx, int stream, const int32_t* wo
     RC_HIP(hipSetDevice(ctx->device));
     RC_HIP(hipMemcpyAsync(s->an.hist.p, words, RC_HIST_WORDS * 4, hipMemcpyHostToDevice, s->cur));
     RC_HIP(hipStreamSynchronize(s->cur));
+    s->an.hist_added = words[RC_HIST_BINS + RC_HIST_DIRECTIONS * RC_HIST_BINS];     // histsum
+    return RC_OK;
+}
+
+// Starts a new segment: zeroes the cumulative counters on the slot's stream (thresholds, accumulator and
+// particles are left alone).  Asynchronous.
+extern "C" int rcflow_histogram_reset_dev(rc_ctx* ctx, int stream) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    if (!s->an.hist.p) { rc_set_error("no histogram state: call rcflow_analysis_reset first"); return RC_ESTATE; }
+    RC_HIP(hipSetDevice(ctx->device));
+    RC_HIP(hipMemsetAsync(s->an.hist.p, 0, RC_HIST_WORDS * sizeof(int), s->cur));
+    s->an.hist_added = 0;
     return RC_OK;
 }
 

@@ -1059,45 +1059,44 @@ static void launch_w3x2_t(RcIterArgs a, int pairs, hipStream_t s) {
 // (the compiler's DPP combiner folds only some of the equivalent builtin calls).  s_nop 1 covers
 // the two wait states a DPP read needs after a VALU write of its source.
 __device__ __forceinline__ void rc_hsum3_dpp(float (&g)[5], const float (&V)[5]) {
+    // ONE asm statement: the compiler cannot place a copy or a reload of V between the two DPP groups,
+    // so the only VALU write a DPP read can follow too closely is the one before the statement (s_nop 1),
+    // and the second group reads V again five instructions after the first (its t operands are plain reads).
     float t0, t1, t2, t3, t4;
     asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %2, %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %3, %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %4, %9, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
+        "v_add_f32_dpp %5, %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %6, %11, %11 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %7, %12, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %8, %13, %13 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %9, %14, %14 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %10, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %11, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %12, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %13, %8 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %14, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]),
+          "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
         : "v"(V[0]), "v"(V[1]), "v"(V[2]), "v"(V[3]), "v"(V[4]));
-    // (no wait states here: the DPP operand is V again, written at least five instructions ago)
-    asm("v_add_f32_dpp %0, %5, %10 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %6, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %2, %7, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %3, %8, %13 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %4, %9, %14 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4])
-        : "v"(V[0]), "v"(V[1]), "v"(V[2]), "v"(V[3]), "v"(V[4]), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(t4));
 }
 
 
-// s[c] = V[c] of lane - 1  +  V[c] of lane + 1
+// s[c] = V[c] of lane - 1  +  V[c] of lane + 1   (one asm statement, see rc_hsum3_dpp)
 __device__ __forceinline__ void rc_hpair_dpp(float (&s)[5], const float (&V)[5]) {
     float t0, t1, t2, t3, t4;
     asm("s_nop 1\n\t"
-        "v_mov_b32_dpp %0, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_mov_b32_dpp %1, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_mov_b32_dpp %2, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_mov_b32_dpp %3, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_mov_b32_dpp %4, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
+        "v_mov_b32_dpp %5, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32_dpp %6, %11 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32_dpp %7, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32_dpp %8, %13 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32_dpp %9, %14 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %10, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %11, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %12, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %13, %8 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %14, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3]), "=&v"(s[4]),
+          "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
         : "v"(V[0]), "v"(V[1]), "v"(V[2]), "v"(V[3]), "v"(V[4]));
-    // (no wait states here: the DPP operand is V again, written at least five instructions ago)
-    asm("v_add_f32_dpp %0, %5, %10 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %6, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %2, %7, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %3, %8, %13 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %4, %9, %14 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3]), "=&v"(s[4])
-        : "v"(V[0]), "v"(V[1]), "v"(V[2]), "v"(V[3]), "v"(V[4]), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(t4));
 }
 
 template <int GAUSS_, int NIT, int MW, int NG>

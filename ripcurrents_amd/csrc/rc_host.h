@@ -29,6 +29,7 @@ struct RcPlan {
 struct RcAnalysis {
     int w = 0, h = 0;
     RcBuf hist;        // RC_HIST_WORDS int32
+    long long hist_added = 0;   // pixels passed to the histogram since the last reset (upper bound of histsum)
     RcBuf hist_part;   // partial hist2d tables of the histogram kernel
     RcBuf thr;         // UPPER | UPPER2d[36] | prop[36] floats (+1 pad)
     RcBuf acc;         // h*w float accumulator (.x channel of the reference's 32FC3)

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_prints_one_contract_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--pairs", "16",
-                          "--cpu-pairs", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--cpu-pairs", "1", "--warmup-seconds", "0.2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -30,7 +30,12 @@ def test_bench_prints_one_contract_line():
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["avg_us"] > 0
-    assert r["compulsory"]["frac"] < 1.0 and r["peak_measured"]["read"] > 1000
+    # a roofline fraction is physical: compulsory bytes of the launch as built / time / 8 TB/s
+    assert 0.0 < r["frac"] < 1.0 and r["peak_measured"]["read"] > 1000
+    assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9) / r["achieved"] < 0.01
+    assert "traffic_source" in r and (r["traffic"] is None or r["traffic_source"])
+    assert 0.0 < j["pipeline"]["frac"] < 1.0 and all(0.0 < k["frac"] < 1.0 for k in j["kernels"])
+    assert j["warmup_steps_run"] >= 1
     c = j["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -46,7 +51,7 @@ def test_bench_two_ranks_rehearsal():
     port = 29600 + os.getpid() % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--pairs", "4", "--no-roof"]
+           "--pairs", "4", "--no-roof", "--warmup-seconds", "0.2"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
