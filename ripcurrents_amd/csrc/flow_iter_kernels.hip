@@ -22,6 +22,20 @@
 
 #define RC_ITER_BATCH 3
 
+// This file is compiled twice.  The default build (namespace rc_flow_fast) is the fast arithmetic:
+// sums of products as fused multiply-adds, the winsize-3 solve in fp32 (Kahan).  With -DRC_EXACT_BUILD
+// (namespace rc_flow_exact, object flow_iter_kernels_exact.o) the SAME kernels evaluate
+// FarnebackUpdateMatrices in optflow.cpp's operation order without fused multiply-adds and solve every 2x2
+// system in double like upstream: together with the Gaussian window sums -- which are upstream's order in
+// both builds -- the iteration is then bit-identical to the CPU path.  Option "exact" selects that build
+// for Gaussian windows (box windows need upstream's running sums: exact_kernels.hip).
+#ifdef RC_EXACT_BUILD
+#define RC_FLOW_NS rc_flow_exact
+#else
+#define RC_FLOW_NS rc_flow_fast
+#endif
+namespace RC_FLOW_NS {
+
 // resize(prevFlow, INTER_LINEAR) then flow *= 1/pyr_scale (optflow.cpp calc()), or the
 // same-resolution flow of the previous iteration, or zeros at the coarsest scale.
 __device__ __forceinline__ float2 rc_flow_in(const RcIterArgs& a, const float2* fin, int gx, int gy) {
@@ -77,7 +91,11 @@ __device__ __forceinline__ RcM5 rc_matrices_reg(const float4 A0, const float B0,
     float fx = g.fx, fy = g.fy;
     float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy);
     float a10 = (1.f - fx) * fy, a11 = fx * fy;
+#ifdef RC_EXACT_BUILD
+#define RC_BILIN(c, e) (a00 * e##00 c + a01 * e##01 c + a10 * e##10 c + a11 * e##11 c)
+#else
 #define RC_BILIN(c, e) RC_FMA(a11, e##11 c, RC_FMA(a10, e##10 c, RC_FMA(a01, e##01 c, a00 * e##00 c)))
+#endif
     float r2 = RC_BILIN(.x, g.q), r3 = RC_BILIN(.y, g.q), r4 = RC_BILIN(.z, g.q), r5 = RC_BILIN(.w, g.q);
     float r6 = RC_BILIN(, g.e);
 #undef RC_BILIN
@@ -92,8 +110,13 @@ __device__ __forceinline__ RcM5 rc_matrices_reg(const float4 A0, const float B0,
     }
     r2 = (A0.x - r2) * 0.5f;
     r3 = (A0.y - r3) * 0.5f;
+#ifdef RC_EXACT_BUILD
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+#else
     r2 = RC_FMA(r6, dx, RC_FMA(r4, dy, r2));
     r3 = RC_FMA(r5, dx, RC_FMA(r6, dy, r3));
+#endif
     if (BORDER && ((unsigned)(X - 5) >= (unsigned)(w - 10) || (unsigned)(Y - 5) >= (unsigned)(h - 10))) {
         float bl = X < 5 ? (X < 2 ? 0.14f : 0.4472f) : 1.f;
         int rx = w - X - 1;
@@ -105,11 +128,19 @@ __device__ __forceinline__ RcM5 rc_matrices_reg(const float4 A0, const float B0,
         r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
     }
     RcM5 o;
+#ifdef RC_EXACT_BUILD
+    o.m0 = r4 * r4 + r6 * r6;
+    o.m1 = (r4 + r5) * r6;
+    o.m2 = r5 * r5 + r6 * r6;
+    o.m3 = r4 * r2 + r6 * r3;
+    o.m4 = r6 * r2 + r5 * r3;
+#else
     o.m0 = RC_FMA(r4, r4, r6 * r6);
     o.m1 = (r4 + r5) * r6;
     o.m2 = RC_FMA(r5, r5, r6 * r6);
     o.m3 = RC_FMA(r4, r2, r6 * r3);
     o.m4 = RC_FMA(r6, r2, r5 * r3);
+#endif
     return o;
 }
 
@@ -144,6 +175,12 @@ __device__ __forceinline__ float rc_diff_of_products(float a, float b, float c, 
     return f + e;
 }
 __device__ __forceinline__ float2 rc_solve3(const float* g, float eps) {
+#ifdef RC_EXACT_BUILD
+    // upstream's solve (Gaussian windows only reach this build: the float window values, widened)
+    (void)eps;
+    const double d[5] = {g[0], g[1], g[2], g[3], g[4]};
+    return rc_solve(d);
+#endif
     float det = rc_diff_of_products(g[0], g[2], g[1], g[1]) + eps;
     float nx = rc_diff_of_products(g[0], g[4], g[1], g[3]);
     float ny = rc_diff_of_products(g[2], g[3], g[1], g[4]);
@@ -1469,3 +1506,5 @@ void rc_launch_flow_iter(const RcIterArgs& a, int pairs, hipStream_t s) {
     RC_ALLOW_LDS((k_flow_iter<0, 0, 0, 0>), lds);
     hipLaunchKernelGGL((k_flow_iter<0, 0, 0, 0>), dim3(b.tiles_x * b.tiles_y, pairs, 1), dim3(RC_BLOCK), lds, s, b);
 }
+
+}  // namespace RC_FLOW_NS

@@ -188,10 +188,14 @@ int rc_pyr_pair_ok(const RcPyrArgs& a1, const RcPyrArgs& a2);
 void rc_launch_pyr_pair(const RcPyrArgs& a1, const RcPyrArgs& a2, int frames, hipStream_t s);
 int rc_polyexp_multi_ok(const RcPolyArgs* a, int nlev);
 void rc_launch_polyexp_multi(const RcPolyArgs* a, int nlev, int frames, hipStream_t s);
-void rc_launch_flow_iter(const RcIterArgs& a, int pairs, hipStream_t s);
-// two iterations in one launch (only where rc_flow_iter_can_fuse2 says so)
-int rc_flow_iter_can_fuse2(const RcIterArgs& a);
-void rc_launch_flow_iter2(const RcIterArgs& a, int pairs, hipStream_t s);
+// flow_iter_kernels.hip is built twice: fast arithmetic, and upstream's operation order (Gaussian windows)
+#define RC_FLOW_DECLS                                                         \
+    void rc_launch_flow_iter(const RcIterArgs& a, int pairs, hipStream_t s);  \
+    /* two iterations in one launch (only where rc_flow_iter_can_fuse2 says so) */ \
+    int rc_flow_iter_can_fuse2(const RcIterArgs& a);                          \
+    void rc_launch_flow_iter2(const RcIterArgs& a, int pairs, hipStream_t s);
+namespace rc_flow_fast { RC_FLOW_DECLS }
+namespace rc_flow_exact { RC_FLOW_DECLS }
 
 // interleave helpers for the stage-level test entry points
 void rc_launch_pack_R5(const float* R5, float4* RA, float* RB, int n, hipStream_t s);

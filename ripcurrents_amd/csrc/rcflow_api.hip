@@ -696,7 +696,11 @@ static int compute_flows_exact(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, flo
 // Coarse-to-fine flow for `pairs` frame pairs whose expansions sit in slots slot0+z, slot0+z+1.
 static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_out, size_t out_pair_stride,
                          size_t out_step, int slot1 = -1, int zstep = 1) {
-    if (s.plan.exact) return compute_flows_exact(ctx, s, pairs, slot0, d_out, out_pair_stride, out_step, slot1, zstep);
+    // option "exact": box windows replay upstream's running sums (exact_kernels.hip); Gaussian windows run the
+    // kernels below from the build of flow_iter_kernels.hip that keeps upstream's operation order
+    if (s.plan.exact && !s.plan.win.gaussian)
+        return compute_flows_exact(ctx, s, pairs, slot0, d_out, out_pair_stride, out_step, slot1, zstep);
+    const bool exact = s.plan.exact != 0;
     RcPlan& pl = s.plan;
     const int iters = pl.prm.iterations;
     const float2* coarse = nullptr;
@@ -734,7 +738,7 @@ static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_
             }
             a.solve = iters > 0 ? 1 : 0;
             // two iterations per launch whenever two are left and the window allows it
-            int fuse = (passes - i >= 2 && ctx->fuse_iters && rc_flow_iter_can_fuse2(a)) ? 2 : 1;
+            int fuse = (passes - i >= 2 && ctx->fuse_iters && rc_flow_fast::rc_flow_iter_can_fuse2(a)) ? 2 : 1;
             bool last = (i + fuse == passes);
             if (last && k == 0) {
                 a.fout = (char*)d_out; a.fout_step = out_step; a.fout_pair_stride = out_pair_stride;
@@ -753,8 +757,13 @@ static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_
                 for (int j = i; j < i + fuse; j++) model += (j == passes - 1) ? 28. * n : 80. * n;
                 RcProfScope ps(ctx, s.cur, fuse == 2 ? RC_K_ITER2 : RC_K_ITER, k,
                                (double)pairs * ((a.solve ? 40. : 0.) * n + in_bytes + 8. * n), (double)pairs * model);
-                if (fuse == 2) rc_launch_flow_iter2(a, pairs, s.cur);
-                else rc_launch_flow_iter(a, pairs, s.cur);
+                if (exact) {
+                    if (fuse == 2) rc_flow_exact::rc_launch_flow_iter2(a, pairs, s.cur);
+                    else rc_flow_exact::rc_launch_flow_iter(a, pairs, s.cur);
+                } else {
+                    if (fuse == 2) rc_flow_fast::rc_launch_flow_iter2(a, pairs, s.cur);
+                    else rc_flow_fast::rc_launch_flow_iter(a, pairs, s.cur);
+                }
             }
             i += fuse;
         }
@@ -1154,7 +1163,7 @@ extern "C" int rcflow_stage_flow_iter_dev(rc_ctx* ctx, int stream, const float* 
     a.in_mode = d_flow_in ? 1 : 0; a.fin = (const float2*)d_flow_in; a.fin_pair_stride = n;
     a.fout = (char*)d_flow_out; a.fout_step = (size_t)w * 8; a.fout_pair_stride = n * 8;
     a.solve = 1; a.win = win; a.xcd_remap = ctx->xcd_remap;
-    rc_launch_flow_iter(a, 1, s->cur);
+    rc_flow_fast::rc_launch_flow_iter(a, 1, s->cur);
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
