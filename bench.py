@@ -23,6 +23,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -82,9 +84,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roof", action="store_true", help="skip the measured memory roof (read/fill/copy microbench)")
     ap.add_argument("--cpu-pairs", type=int, default=6)
+    ap.add_argument("--collective", choices=["torch", "rccl"], default="torch",
+                    help="N>1: torch.distributed all_reduce (default) or the library's C-ABI collective "
+                         "(rcflow_allreduce_hist over librccl)")
     ap.add_argument("--sync-collective", action="store_true", help="N>1: all-reduce and thresholds inside the step (no one-step pipelining)")
     ap.add_argument("--clip-per-step", action="store_true", help="every step is an independent clip of pairs + 1 frames (pairs + 1 expansions)")
     ap.add_argument("--gaussian", action="store_true", help="main.cpp:264 variant (flags=256)")
+    ap.add_argument("--mode", choices=["clip", "frame", "host", "host-stateless"], default="clip",
+                    help="clip (default, the headline): 32 resident frames per call.  The reference-shaped loops, "
+                         "reported under their own metric name, never as the headline: frame = one resident frame per "
+                         "call (rcflow_push_frame_dev); host = frames from host memory through the page-locked double "
+                         "buffer, flow stays on the device (rcflow_push_frame_u8; PCIe-inclusive upload); host-stateless = "
+                         "the literal two-image drop-in with host pointers and the flow copied back (rcflow_farneback_u8)")
     args = ap.parse_args()
 
     import torch
@@ -112,7 +123,7 @@ def main():
 
     from ripcurrents_amd import synth
     from ripcurrents_amd.api import Context
-    from ripcurrents_amd.distributed import allreduce_hist_words, allreduce_hist_words_async
+    from ripcurrents_amd.distributed import allreduce_hist_words, allreduce_hist_words_async, init_comm
 
     params = dict(PARAMS)
     if args.gaussian:
@@ -125,12 +136,19 @@ def main():
         ctx.set_option("chunk", args.chunk)
     ctx.analysis_reset(W, H)
     hist_words = ctx.histogram_words()
+    use_cabi = world > 1 and args.collective == "rccl" and not rehearse
+    if use_cabi:
+        init_comm(ctx)
 
     pending = []
+    cabi_pending = []
 
     def finish_pending():
         while pending:
             ctx.thresholds_from_words(pending.pop(0).wait())
+        while cabi_pending:
+            ctx.allreduce_hist_join()
+            ctx.thresholds_from_words(cabi_pending.pop())
 
     # The segment is a stream: every step pushes the next `pairs` frames (rcflow_push_clip_dev), the slot keeps
     # the last frame's expansion, so every frame is expanded exactly once (SURVEY 8(d)'s streaming model).  The
@@ -138,7 +156,17 @@ def main():
     # neighbours in the clip.  --clip-per-step restores independent clips of pairs + 1 frames per step.
     fwd = frames[1:]
     bwd = frames.flip(0)[1:].contiguous()
-    if not args.clip_per_step:
+    host_fwd = host_bwd = host_flow = None
+    host_last = [None]
+    if args.mode in ("host", "host-stateless"):
+        host_fwd = fwd.cpu().numpy()
+        host_bwd = bwd.cpu().numpy()
+        host_last[0] = frames[0].cpu().numpy()
+        host_flow = np.empty((H, W, 2), np.float32)
+    if args.mode == "host":
+        ctx.stream_reset()
+        ctx.push_frame_host(host_last[0], **params)
+    elif args.mode == "frame" or not args.clip_per_step:
         ctx.stream_reset()
         ctx.push_clip(frames[0:1], flows, **params)          # primes the stream, no flow
     nstep = [0]
@@ -147,7 +175,27 @@ def main():
         # a step is one segment of `pairs` frames: its histogram starts from zero (int32 counters:
         # 32 x 2.07 M counts per step; cumulative over the run they would wrap after ~32 steps)
         ctx.histogram_reset()
-        if args.clip_per_step:
+        if args.mode == "frame":
+            seq = fwd if nstep[0] % 2 == 0 else bwd
+            for t in range(args.pairs):
+                ctx.push_frame(seq[t], flows[t], **params)
+            nstep[0] += 1
+        elif args.mode == "host":
+            seq = host_fwd if nstep[0] % 2 == 0 else host_bwd
+            for t in range(args.pairs):
+                f = ctx.push_frame_host(seq[t], **params)
+                flows[t].copy_(f, non_blocking=True)       # device-side copy into the step's batch (the analysis input)
+            nstep[0] += 1
+        elif args.mode == "host-stateless":
+            seq = host_fwd if nstep[0] % 2 == 0 else host_bwd
+            prev = host_last[0]
+            for t in range(args.pairs):
+                ctx.calcOpticalFlowFarneback(prev, seq[t], host_flow, **params)
+                prev = seq[t]
+            host_last[0] = prev
+            nstep[0] += 1
+            return                                           # the flow is on the host: no device-side analysis
+        elif args.clip_per_step:
             ctx.farneback_clip(frames, flows, **params)
         else:
             got = ctx.push_clip(fwd if nstep[0] % 2 == 0 else bwd, flows, **params)
@@ -159,7 +207,19 @@ def main():
             # rank then derives the same global thresholds from the same integers.  The 7.5 KB
             # collective of step k runs on RCCL's stream beside the flow kernels of step k+1 and
             # its thresholds are derived one step later (all of them inside the timed region).
-            if args.sync_collective:
+            if use_cabi:
+                # C-ABI collective: starts on its own stream; the thresholds of step k are enqueued behind it
+                # at step k+1 (or right away with --sync-collective)
+                if not args.sync_collective and cabi_pending:
+                    ctx.allreduce_hist_join()
+                    ctx.thresholds_from_words(cabi_pending.pop())
+                g = ctx.allreduce_hist()
+                if args.sync_collective:
+                    ctx.allreduce_hist_join()
+                    ctx.thresholds_from_words(g)
+                else:
+                    cabi_pending.append(g)
+            elif args.sync_collective:
                 ctx.thresholds_from_words(allreduce_hist_words(hist_words))
             else:
                 nxt = allreduce_hist_words_async(hist_words)
@@ -224,8 +284,11 @@ def main():
         frames_done = world * args.pairs * args.steps
         fps = frames_done / elapsed
         model_b = survey_model_bytes_per_frame(W, H, params["levels"], params["iterations"])
+        mode_names = {"clip": "", "frame": " [one resident frame per call]", "host": " [host frames, PCIe upload inclusive, flow resident]",
+                      "host-stateless": " [two-image host-pointer drop-in, PCIe both ways, blocking]"}
         out = {
-            "metric": "frames/sec dense Farneback flow @1080p",
+            "metric": "frames/sec dense Farneback flow @1080p" + mode_names[args.mode],
+            "mode": args.mode, "headline": args.mode == "clip",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -239,7 +302,8 @@ def main():
                                       "the next %d frames of a continuing segment per step (streaming model: every frame "
                                       "expanded once; the clip is played forwards and backwards)" % args.pairs),
                        "pairs_per_step": args.pairs, "segments": world,
-                       "collective": ("all_reduce int32[1887] per step" + ("" if args.sync_collective else ", overlapped with the next step")) if world > 1 else "none"},
+                       "collective": ("all_reduce int32[1887] per step" + ("" if args.sync_collective else ", overlapped with the next step")
+                                      + (" (rcflow_allreduce_hist, librccl)" if use_cabi else " (torch.distributed)")) if world > 1 else "none"},
             "warmup_steps_run": warm_run,
             "survey_model": {"bytes_per_frame": model_b,
                              "frac_of_8TBs": round(fps / world * model_b / (HBM_PEAK_GBS * 1e9), 4),

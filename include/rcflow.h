@@ -125,6 +125,16 @@ int rcflow_farneback_dev(rc_ctx* ctx, int stream, const uint8_t* d_prev, size_t 
 int rcflow_push_frame_dev(rc_ctx* ctx, int stream, const uint8_t* d_frame, size_t step,
                           int w, int h, float* d_flow_xy, size_t flow_step,
                           const rc_farneback_params* p);
+/* The same loop with HOST frames, as the reference holds them after video.read / resize / cvtColor
+ * (ripcurrents.cpp:198-213): the frame is copied into one of two page-locked staging buffers and uploaded
+ * asynchronously; the call returns once the copy into the staging buffer is done, so upload and kernels of frame t
+ * overlap the host's decode of frame t + 1.  The flow field stays on the device (rcflow_stream_flow_ptr: input of the
+ * analysis entry points) and crosses PCIe only through rcflow_stream_flow_read.  Returns 1 when the call primed the
+ * stream.  Interoperates with rcflow_push_frame_dev / rcflow_push_clip_dev on the same slot. */
+int rcflow_push_frame_u8(rc_ctx* ctx, int stream, const uint8_t* frame, size_t step, int w, int h,
+                         const rc_farneback_params* p);
+int rcflow_stream_flow_ptr(rc_ctx* ctx, int stream, float** d_flow_xy, int* w, int* h);
+int rcflow_stream_flow_read(rc_ctx* ctx, int stream, float* flow_xy, size_t flow_step);
 /* Batched form of the same stream: the nframes frames continue the slot's stream, every frame is expanded
  * once however the segment is cut into calls.  Returns the number of flow fields written to d_flows[0..):
  * nframes if the stream was primed (flow 0 = last frame of the previous call -> d_frames[0]), nframes - 1 if
@@ -305,6 +315,29 @@ int rcflow_pyrlk_u8(rc_ctx* ctx, int stream, const uint8_t* prev, size_t prev_st
 /* last pyramid level buildOpticalFlowPyramid keeps for this size and window */
 int rcflow_pyrlk_levels(int w, int h, int win_w, int win_h, int max_level);
 
+/* ------------------------------------------------------------------ multi-GPU: the global flow histogram
+ * one process per GPU, each on its own video segment; the only exchange is the integer sum of
+ * the RC_HIST_WORDS histogram counters (7548 B) over RCCL, after which every rank derives the same global
+ * UPPER / UPPER2d / prop_above_upper (what ripcurrents.cpp:333-366 computes from one stream's counters).
+ * librccl is opened at run time by these calls only.  A world of one rank is the identity and needs no RCCL. */
+#define RC_COMM_ID_BYTES 128   /* sizeof(ncclUniqueId) */
+/* rank 0: creates the id; the host distributes it to the other ranks (MPI, a socket, a file) */
+int rcflow_comm_unique_id(void* id_out /* RC_COMM_ID_BYTES */);
+/* every rank, collectively: joins the communicator on the context's GPU.  RC_ECOMM when RCCL fails. */
+int rcflow_comm_init(rc_ctx* ctx, const void* unique_id /* RC_COMM_ID_BYTES; may be NULL when world == 1 */,
+                     int rank, int world);
+int rcflow_comm_destroy(rc_ctx* ctx);
+int rcflow_comm_rank(rc_ctx* ctx, int* rank, int* world);
+/* Starts the sum over all ranks of the slot's histogram counters as they are at this point of the slot's
+ * stream; the result goes to d_words_out (device, RC_HIST_WORDS int32) or, when NULL, to a context-owned
+ * buffer (rcflow_allreduce_hist_result).  Asynchronous and off the slot's stream: the collective runs on its
+ * own HIP stream beside whatever the slot does next.  RC_ESTATE if the sum could exceed int32. */
+int rcflow_allreduce_hist(rc_ctx* ctx, int stream, int32_t* d_words_out);
+/* Orders the slot's stream after the collective started last (no host wait): call it before
+ * rcflow_thresholds_words_dev(ctx, stream, d_words_out). */
+int rcflow_allreduce_hist_join(rc_ctx* ctx, int stream);
+int rcflow_allreduce_hist_result(rc_ctx* ctx, int32_t** d_words);
+
 /* ------------------------------------------------------------------ measurement */
 /* When enabled every kernel launch is bracketed by HIP events on the slot's stream.  Measurement
  * aid: while it is on, drive the context from one thread only (the event list is per context). */
@@ -316,6 +349,14 @@ int rcflow_profile_reset(rc_ctx* ctx);
  * 8(d)'s algorithmic bytes of the stages those launches stand for. */
 int rcflow_profile_read(rc_ctx* ctx, int cap, const char** names, int* launches,
                         double* total_ms, double* alg_bytes, double* model_bytes);
+
+/* The same totals under the reference's own bucket names, in the order it prints them (ripcurrents.cpp:103-109,
+ * :518-524): farneback, polar, threshold, overlay, erosion, codec, stream ("pathlines").  GPU time of the kernels
+ * that do each bucket's work; "polar" is 0 (the cartToPolar of :305-309 is fused into the histogram and
+ * classification kernels, booked under "threshold"), "codec" is 0 (video decode is host I/O outside the library).
+ * names / ms: RC_PROFILE_BUCKETS entries each (either may be NULL).  Returns RC_PROFILE_BUCKETS. */
+#define RC_PROFILE_BUCKETS 7
+int rcflow_profile_read_buckets(rc_ctx* ctx, const char** names, double* ms);
 
 /* The memory roof this device actually reaches: streaming read, fill and copy
  * (read + write bytes) in GB/s over scratch buffers of `bytes` (use >= 1 GiB: beyond the Infinity

@@ -67,6 +67,7 @@ class Pipeline {
             hip_check(hipMalloc(&d_frames_, (size_t)2 * w_ * h_), "hipMalloc frames");
             hip_check(hipMalloc(&d_flow_, (size_t)w_ * h_ * 8), "hipMalloc flow");
             hip_check(hipMalloc(&d_mask_, (size_t)w_ * h_), "hipMalloc mask");
+            flow_src_ = (const float*)d_flow_;
             check(rcflow_analysis_reset(ctx_, 0, w_, h_));
         } catch (...) {
             release();
@@ -78,7 +79,7 @@ class Pipeline {
     Pipeline& operator=(const Pipeline&) = delete;
 
     rc_ctx* context() { return ctx_; }
-    const float* device_flow() const { return (const float*)d_flow_; }
+    const float* device_flow() const { return flow_src_; }
 
     // cv::calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, iterations,
     // poly_n, poly_sigma, flags): 8UC1 in, CV_32FC2 out (flow.data may be null: the field then
@@ -87,22 +88,23 @@ class Pipeline {
     // u_f1.copyTo(u_f2)) with the previous frame kept on the device: one upload and one pyramid + expansion
     // per frame (rcflow_push_frame_dev).  Returns false for the call that primes the stream (the first one, or
     // the first with other parameters): no flow yet.  The flow equals calcOpticalFlowFarneback(previous, frame).
+    // The upload goes through the library's page-locked double buffer (rcflow_push_frame_u8) and is
+    // asynchronous: with a null `flow` view the call returns while upload and kernels are still running, and the
+    // analysis calls below queue behind them on the same stream; only a non-null `flow` waits and downloads.
     bool pushFrame(const Mat& frame, Mat& flow, double pyr_scale, int levels, int winsize, int iterations, int poly_n,
                    double poly_sigma, int flags) {
         if (frame.empty() || frame.channels != 1 || frame.elem != 1 || frame.cols != w_ || frame.rows != h_)
             throw Error(RC_EINVAL, "pushFrame: frame must be 8UC1 of the pipeline's size");
-        uint8_t* df = (uint8_t*)d_frames_;
-        hip_check(hipMemcpy2D(df, w_, frame.data, frame.step, w_, h_, hipMemcpyHostToDevice), "upload frame");
+        if (flow.data && (flow.rows != h_ || flow.cols != w_ || flow.channels != 2 || flow.elem != 4))
+            throw Error(RC_EINVAL, "flow must be CV_32FC2 of the frame size");
         rc_farneback_params p = {pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags};
-        const int rc = rcflow_push_frame_dev(ctx_, 0, df, w_, w_, h_, (float*)d_flow_, (size_t)w_ * 8, &p);
+        const int rc = rcflow_push_frame_u8(ctx_, 0, (const uint8_t*)frame.data, frame.step, w_, h_, &p);
         check(rc);
-        check(rcflow_sync(ctx_, 0));
         if (rc == 1) return false;
-        if (flow.data) {
-            if (flow.rows != h_ || flow.cols != w_ || flow.channels != 2 || flow.elem != 4)
-                throw Error(RC_EINVAL, "flow must be CV_32FC2 of the frame size");
-            hip_check(hipMemcpy2D(flow.data, flow.step, d_flow_, (size_t)w_ * 8, (size_t)w_ * 8, h_, hipMemcpyDeviceToHost), "download flow");
-        }
+        float* d = nullptr;
+        check(rcflow_stream_flow_ptr(ctx_, 0, &d, nullptr, nullptr));
+        flow_src_ = d;                                  // the analysis calls read the stream's resident field
+        if (flow.data) check(rcflow_stream_flow_read(ctx_, 0, (float*)flow.data, flow.step));
         return true;
     }
 
@@ -116,6 +118,7 @@ class Pipeline {
         hip_check(hipMemcpy2D(df + (size_t)w_ * h_, w_, next.data, next.step, w_, h_, hipMemcpyHostToDevice), "upload next");
         rc_farneback_params p = {pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags};
         check(rcflow_farneback_dev(ctx_, 0, df, w_, df + (size_t)w_ * h_, w_, w_, h_, (float*)d_flow_, (size_t)w_ * 8, &p));
+        flow_src_ = (float*)d_flow_;
         check(rcflow_sync(ctx_, 0));
         if (flow.data) {
             if (flow.rows != h_ || flow.cols != w_ || flow.channels != 2 || flow.elem != 4)
@@ -142,10 +145,9 @@ class Pipeline {
         uint8_t* df = (uint8_t*)d_frames_;
         hip_check(hipMemcpy2D(df, w_, prev.data, prev.step, w_, h_, hipMemcpyHostToDevice), "upload prev");
         hip_check(hipMemcpy2D(df + (size_t)w_ * h_, w_, next.data, next.step, w_, h_, hipMemcpyHostToDevice), "upload next");
-        void* d = nullptr;      // prevPts | nextPts | err | status
+        // prevPts | nextPts | err | status in the pipeline's grow-only scratch buffer (no allocation in the frame loop)
         const size_t off_n = (size_t)n * 8, off_e = 2 * off_n, off_s = off_e + (size_t)n * 4;
-        hip_check(hipMalloc(&d, off_s + n), "point buffers");
-        char* b = (char*)d;
+        char* b = (char*)scratch(off_s + n);
         hipError_t e = hipMemcpy(b, prevPts.data(), off_n, hipMemcpyHostToDevice);
         if (e == hipSuccess && initial) e = hipMemcpy(b + off_n, nextPts.data(), off_n, hipMemcpyHostToDevice);
         int rc = e == hipSuccess ? rcflow_pyrlk_dev(ctx_, 0, df, w_, df + (size_t)w_ * h_, w_, w_, h_, (const float*)b,
@@ -158,7 +160,6 @@ class Pipeline {
             if (e == hipSuccess) e = hipMemcpy(err.data(), b + off_e, (size_t)n * 4, hipMemcpyDeviceToHost);
             if (e == hipSuccess) e = hipMemcpy(status.data(), b + off_s, n, hipMemcpyDeviceToHost);
         }
-        (void)hipFree(d);
         check(rc);
         hip_check(e, "PyrLK point transfer");
     }
@@ -168,6 +169,7 @@ class Pipeline {
         if (current.rows != h_ || current.cols != w_ || current.channels != 2 || current.elem != 4)
             throw Error(RC_EINVAL, "current must be CV_32FC2 of the frame size");
         hip_check(hipMemcpy2D(d_flow_, (size_t)w_ * 8, current.data, current.step, (size_t)w_ * 8, h_, hipMemcpyHostToDevice), "upload flow");
+        flow_src_ = (float*)d_flow_;
     }
 
     // create_histogram(current, hist, histsum, hist2d, histsum2d, UPPER, UPPER2d, prop_above_upper)
@@ -176,7 +178,7 @@ class Pipeline {
     void create_histogram(int hist[RC_HIST_BINS], int& histsum, int hist2d[RC_HIST_DIRECTIONS][RC_HIST_BINS],
                           int histsum2d[RC_HIST_DIRECTIONS], float& UPPER, float UPPER2d[RC_HIST_DIRECTIONS],
                           float prop_above_upper[RC_HIST_DIRECTIONS]) {
-        check(rcflow_histogram_dev(ctx_, 0, (const float*)d_flow_, (size_t)w_ * 8, w_, h_));
+        check(rcflow_histogram_dev(ctx_, 0, flow_src_, (size_t)w_ * 8, w_, h_));
         check(rcflow_thresholds_dev(ctx_, 0));
         int32_t hs = 0;
         check(rcflow_histogram_read(ctx_, 0, hist, &hist2d[0][0], &hs, histsum2d, &UPPER, UPPER2d, prop_above_upper));
@@ -186,7 +188,7 @@ class Pipeline {
     // create_flow + create_accumulationbuffer in one pass; outmask (8UC1, may be null view)
     // receives the wave mask.  UPPER / UPPER2d are the slot's (from create_histogram).
     void create_flow_and_accumulationbuffer(Mat& outmask, int framecount, float MID = 0.5f, float LOWER = 0.2f) {
-        check(rcflow_classify_accumulate_dev(ctx_, 0, (const float*)d_flow_, (size_t)w_ * 8, w_, h_, framecount, MID,
+        check(rcflow_classify_accumulate_dev(ctx_, 0, flow_src_, (size_t)w_ * 8, w_, h_, framecount, MID,
                                              LOWER, nullptr, 0, nullptr, 0, nullptr, 0, (uint8_t*)d_mask_, w_));
         check(rcflow_sync(ctx_, 0));
         if (outmask.data)
@@ -197,7 +199,7 @@ class Pipeline {
     // streamlines_mat.forEach(streamline_field(&pixel, distance, x, y, current, dt, iterations,
     // UPPER, prop_above_upper)) -- ripcurrents.cpp:229-231.  UPPER < 0: the slot's UPPER.
     void streamline_field(float dt, int iterations, float UPPER = -1.f) {
-        check(rcflow_advect_field_dev(ctx_, 0, (const float*)d_flow_, (size_t)w_ * 8, w_, h_, dt, iterations, UPPER));
+        check(rcflow_advect_field_dev(ctx_, 0, flow_src_, (size_t)w_ * 8, w_, h_, dt, iterations, UPPER));
     }
     void streamline_field_state(Pixel2* streamlines_mat, float* streamlines_distance) {
         check(rcflow_advect_field_read(ctx_, 0, (float*)streamlines_mat, streamlines_distance));
@@ -217,11 +219,11 @@ class Pipeline {
                     std::vector<Pixel2>* trace = nullptr) {
         if (n <= 0) return;
         const int iters = variant == 2 ? 100 : iterations;
-        void *d_pts = nullptr, *d_tr = nullptr;
-        hip_check(hipMalloc(&d_pts, (size_t)n * 8), "hipMalloc seeds");
-        if (trace) hip_check(hipMalloc(&d_tr, (size_t)n * iters * 8), "hipMalloc trace");
+        const size_t pts_bytes = ((size_t)n * 8 + 255) & ~(size_t)255;
+        char* b = (char*)scratch(pts_bytes + (trace ? (size_t)n * iters * 8 : 0));     // grow-only, no per-frame allocation
+        void *d_pts = b, *d_tr = trace ? b + pts_bytes : nullptr;
         hip_check(hipMemcpy(d_pts, streampt, (size_t)n * 8, hipMemcpyHostToDevice), "upload seeds");
-        int rc = rcflow_advect_points_dev(ctx_, 0, (float*)d_pts, n, (const float*)d_flow_, (size_t)w_ * 8, w_, h_, dt,
+        int rc = rcflow_advect_points_dev(ctx_, 0, (float*)d_pts, n, flow_src_, (size_t)w_ * 8, w_, h_, dt,
                                           iterations, UPPER, variant, (float*)d_tr);
         if (rc == RC_OK) rc = rcflow_sync(ctx_, 0);
         if (rc == RC_OK) {
@@ -231,8 +233,6 @@ class Pipeline {
                 (void)hipMemcpy(trace->data(), d_tr, (size_t)n * iters * 8, hipMemcpyDeviceToHost);
             }
         }
-        (void)hipFree(d_pts);
-        if (d_tr) (void)hipFree(d_tr);
         check(rc);
     }
 
@@ -240,7 +240,21 @@ class Pipeline {
     int height() const { return h_; }
 
   private:
+    // grow-only device scratch for the per-frame helpers (seeds, traces, display image, LK points)
+    void* scratch(size_t bytes) {
+        if (bytes > scratch_bytes_) {
+            check(rcflow_sync(ctx_, 0));
+            if (d_scratch_) (void)hipFree(d_scratch_);
+            d_scratch_ = nullptr; scratch_bytes_ = 0;
+            const size_t want = bytes + bytes / 2;
+            hip_check(hipMalloc(&d_scratch_, want), "hipMalloc scratch");
+            scratch_bytes_ = want;
+        }
+        return d_scratch_;
+    }
     void release() {
+        if (d_scratch_) (void)hipFree(d_scratch_);
+        d_scratch_ = nullptr; scratch_bytes_ = 0;
         if (d_frames_) (void)hipFree(d_frames_);
         if (d_flow_) (void)hipFree(d_flow_);
         if (d_mask_) (void)hipFree(d_mask_);
@@ -251,19 +265,19 @@ class Pipeline {
     void display(int which, Mat& bgr) {
         if (bgr.rows != h_ || bgr.cols != w_ || bgr.channels != 3 || bgr.elem != 1)
             throw Error(RC_EINVAL, "streamoverlay_color must be 8UC3 of the frame size");
-        void* d = nullptr;
-        hip_check(hipMalloc(&d, (size_t)w_ * h_ * 3), "hipMalloc display image");
+        void* d = scratch((size_t)w_ * h_ * 3);
         int rc = rcflow_streamline_display_dev(ctx_, 0, which, (uint8_t*)d, (size_t)w_ * 3, nullptr);
         if (rc == RC_OK) rc = rcflow_sync(ctx_, 0);
         hipError_t e = rc == RC_OK ? hipMemcpy2D(bgr.data, bgr.step, d, (size_t)w_ * 3, (size_t)w_ * 3, h_, hipMemcpyDeviceToHost)
                                    : hipSuccess;
-        (void)hipFree(d);
         check(rc);
         hip_check(e, "download display image");
     }
     rc_ctx* ctx_ = nullptr;
     int w_, h_;
-    void *d_frames_ = nullptr, *d_flow_ = nullptr, *d_mask_ = nullptr;
+    void *d_frames_ = nullptr, *d_flow_ = nullptr, *d_mask_ = nullptr, *d_scratch_ = nullptr;
+    size_t scratch_bytes_ = 0;
+    const float* flow_src_ = nullptr;     // the field the analysis calls read: d_flow_ or the stream's resident field
 };
 
 // Streakline.hpp:8-20.  run(): runLK's bookkeeping (Streakline.cpp:22-71) with the vertices moved

@@ -14,6 +14,7 @@ RC_OK = 0
 RC_FARNEBACK_GAUSSIAN = 256
 HIST_BINS, HIST_DIRECTIONS, HIST_RESOLUTION = 50, 36, 20
 HIST_WORDS = HIST_BINS + HIST_DIRECTIONS * HIST_BINS + 1 + HIST_DIRECTIONS
+COMM_ID_BYTES = 128     # RC_COMM_ID_BYTES = sizeof(ncclUniqueId)
 
 ERRORS = {-1: "RC_EINVAL", -2: "RC_ENOMEM", -3: "RC_EHIP", -4: "RC_ENODEV", -5: "RC_ESIZE",
           -6: "RC_ESTATE", -7: "RC_ECOMM"}
@@ -48,6 +49,9 @@ SIGNATURES = {
     "rcflow_farneback_dev": [_vp, _i, _vp, _sz, _vp, _sz, _i, _i, _vp, _sz, _pp],
     "rcflow_push_frame_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz, _pp],
     "rcflow_stream_reset": [_vp, _i],
+    "rcflow_push_frame_u8": [_vp, _i, _vp, _sz, _i, _i, _pp],
+    "rcflow_stream_flow_ptr": [_vp, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i)],
+    "rcflow_stream_flow_read": [_vp, _i, _vp, _sz],
     "rcflow_farneback_clip_dev": [_vp, _i, _vp, _sz, _sz, _i, _i, _i, _vp, _sz, _sz, _pp],
     "rcflow_push_clip_dev": [_vp, _i, _vp, _sz, _sz, _i, _i, _i, _vp, _sz, _sz, _pp],
     "rcflow_push_batch_dev": [_vp, _i, _vp, _sz, _sz, _i, _i, _i, _vp, _sz, _sz, _pp, _i],
@@ -91,8 +95,16 @@ SIGNATURES = {
     "rcflow_pyrlk_u8": [_vp, _i, _vp, _sz, _vp, _sz, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _d],
     "rcflow_pyrlk_levels": [_i, _i, _i, _i, _i],
     "rcflow_measure_memory_roof": [_vp, _i, _sz, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)],
+    "rcflow_comm_unique_id": [_vp],
+    "rcflow_comm_init": [_vp, _vp, _i, _i],
+    "rcflow_comm_destroy": [_vp],
+    "rcflow_comm_rank": [_vp, C.POINTER(_i), C.POINTER(_i)],
+    "rcflow_allreduce_hist": [_vp, _i, _vp],
+    "rcflow_allreduce_hist_join": [_vp, _i],
+    "rcflow_allreduce_hist_result": [_vp, C.POINTER(_vp)],
     "rcflow_profile_enable": [_vp, _i],
     "rcflow_profile_reset": [_vp],
+    "rcflow_profile_read_buckets": [_vp, C.POINTER(C.c_char_p), C.POINTER(_d)],
     "rcflow_profile_read": [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i), C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)],
 }
 

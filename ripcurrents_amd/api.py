@@ -168,6 +168,31 @@ class Context:
                                                    self._ptr(flow), flow.stride(0) * 4, C.byref(p)))
         return None if rc == 1 else flow
 
+    def push_frame_host(self, frame, stream=0, **kw):
+        """The frame loop with HOST frames (rcflow_push_frame_u8): numpy HxW uint8 in, page-locked
+        double-buffered upload, the flow field stays on the device.  Returns None when the call primed
+        the stream, else a CUDA tensor aliasing the slot's resident flow field (valid until the next push)."""
+        frame = np.asarray(frame)
+        if frame.dtype != np.uint8 or frame.ndim != 2 or frame.strides[1] != 1:
+            frame = np.ascontiguousarray(frame, np.uint8)
+        h, w = frame.shape
+        p = _params(kw.get("pyr_scale", 0.5), kw.get("levels", 2), kw.get("winsize", 3),
+                    kw.get("iterations", 2), kw.get("poly_n", 15), kw.get("poly_sigma", 1.2),
+                    kw.get("flags", 0))
+        self._bind(stream)
+        rc = check(self._lib.rcflow_push_frame_u8(self._h, stream, frame.ctypes.data, frame.strides[0], w, h, C.byref(p)))
+        if rc == 1:
+            return None
+        d = C.c_void_p()
+        check(self._lib.rcflow_stream_flow_ptr(self._h, stream, C.byref(d), None, None))
+        return _alias_tensor(d.value, h * w * 2, torch.float32, self.device).view(h, w, 2)
+
+    def stream_flow_read(self, w, h, stream=0):
+        out = np.empty((h, w, 2), np.float32)
+        self._bind(stream)
+        check(self._lib.rcflow_stream_flow_read(self._h, stream, out.ctypes.data, out.strides[0]))
+        return out
+
     def push_clip(self, frames, flows=None, stream=0, **kw):
         """The next [T,H,W] frames of the slot's stream in one call (rcflow_push_clip_dev): every frame is
         expanded once however the segment is cut into calls.  Returns the flow fields written ([T,H,W,2] when
@@ -339,6 +364,36 @@ class Context:
         """Starts a new segment: zeroes the cumulative counters (asynchronous, on the slot's stream)."""
         self._bind(stream)
         check(self._lib.rcflow_histogram_reset_dev(self._h, stream))
+
+    # ------------------------------------------------------------------ multi-GPU: global histogram (C ABI over RCCL)
+    def comm_unique_id(self):
+        """rank 0: the RCCL unique id (bytes) the host distributes to the other ranks."""
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        check(self._lib.rcflow_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id=None):
+        check(self._lib.rcflow_comm_init(self._h, unique_id, rank, world))
+
+    def comm_destroy(self):
+        check(self._lib.rcflow_comm_destroy(self._h))
+
+    def allreduce_hist(self, stream=0, out=None):
+        """Starts the all-rank sum of the slot's histogram counters (asynchronous, on the collective's own
+        stream); returns the device tensor that will hold the result once allreduce_hist_join() has ordered
+        the slot's stream after it."""
+        self._bind(stream)
+        if out is None:
+            check(self._lib.rcflow_allreduce_hist(self._h, stream, None))
+            p = C.c_void_p()
+            check(self._lib.rcflow_allreduce_hist_result(self._h, C.byref(p)))
+            return _alias_tensor(p.value, HIST_WORDS, torch.int32, self.device)
+        check(self._lib.rcflow_allreduce_hist(self._h, stream, self._ptr(out)))
+        return out
+
+    def allreduce_hist_join(self, stream=0):
+        self._bind(stream)
+        check(self._lib.rcflow_allreduce_hist_join(self._h, stream))
 
     def create_flow_accumulate(self, current, framecount, MID=0.5, LOWER=0.2, want=("polar", "waterclass",
                                "out", "outmask"), stream=0):
@@ -600,6 +655,14 @@ class Context:
         n = check(self._lib.rcflow_profile_read(self._h, cap, names, launches, ms, by, mb))
         return [dict(kernel=names[i].decode(), launches=launches[i], total_ms=ms[i], alg_bytes=by[i],
                      model_bytes=mb[i]) for i in range(n)]
+
+    def profile_read_buckets(self):
+        """GPU time per bucket of the reference's own timing printout (ripcurrents.cpp:518-524):
+        {"farneback": ms, "polar": ms, "threshold": ..., "overlay", "erosion", "codec", "stream"}."""
+        names = (C.c_char_p * 7)()
+        ms = (C.c_double * 7)()
+        n = check(self._lib.rcflow_profile_read_buckets(self._h, names, ms))
+        return {names[i].decode(): ms[i] for i in range(n)}
 
 
 def _alias_tensor(ptr, n, dtype, device):

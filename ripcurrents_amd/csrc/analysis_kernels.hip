@@ -1028,8 +1028,11 @@ extern "C" int rcflow_create_edges_dev(rc_ctx* ctx, int stream, const uint8_t* d
         return RC_EINVAL;
     }
     RC_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_create_edges, dim3((w + 63) / 64, (h + 15) / 16), dim3(RC_BLOCK), 0, s->cur, d_mask, mask_step,
-                       w, h, d_out, out_step);
+    {
+        RcProfScope ps(ctx, s->cur, RC_K_EDGES, 0, 2. * w * h);
+        hipLaunchKernelGGL(k_create_edges, dim3((w + 63) / 64, (h + 15) / 16), dim3(RC_BLOCK), 0, s->cur, d_mask, mask_step,
+                           w, h, d_out, out_step);
+    }
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
@@ -1044,8 +1047,11 @@ extern "C" int rcflow_resize_bgr_to_gray_dev(rc_ctx* ctx, int stream, const uint
     }
     RC_HIP(hipSetDevice(ctx->device));
     double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
-    hipLaunchKernelGGL(k_resize_bgr_to_gray, dim3((dw + 63) / 64, (dh + 3) / 4), dim3(RC_BLOCK), 0, s->cur, d_bgr, step,
-                       sw, sh, d_gray, gray_step, dw, dh, scale_x, scale_y);
+    {
+        RcProfScope ps(ctx, s->cur, RC_K_PREPROC, 0, 3. * sw * sh + 1. * dw * dh);
+        hipLaunchKernelGGL(k_resize_bgr_to_gray, dim3((dw + 63) / 64, (dh + 3) / 4), dim3(RC_BLOCK), 0, s->cur, d_bgr, step,
+                           sw, sh, d_gray, gray_step, dw, dh, scale_x, scale_y);
+    }
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
@@ -1204,11 +1210,14 @@ extern "C" int rcflow_streamline_display_dev(rc_ctx* ctx, int stream, int which,
     unsigned int* key = (unsigned int*)((uint8_t*)s->an.jet.p + 768);
     RC_HIP(hipMemsetAsync(key, 0, 4, s->cur));
     const size_t n = (size_t)w * h;
-    hipLaunchKernelGGL(k_display_max, dim3(1024), dim3(RC_BLOCK), 0, s->cur, (const float2*)s->an.pt.p,
-                       (const float*)s->an.dist.p, n, which, key);
-    hipLaunchKernelGGL(k_display_map, dim3((w + 63) / 64, (h + 3) / 4), dim3(RC_BLOCK), 0, s->cur,
-                       (const float2*)s->an.pt.p, (const float*)s->an.dist.p, w, h, which, key,
-                       (const uint8_t*)s->an.jet.p, d_bgr, bgr_step);
+    {
+        RcProfScope ps(ctx, s->cur, RC_K_DISPLAY, 0, 27. * n);
+        hipLaunchKernelGGL(k_display_max, dim3(1024), dim3(RC_BLOCK), 0, s->cur, (const float2*)s->an.pt.p,
+                           (const float*)s->an.dist.p, n, which, key);
+        hipLaunchKernelGGL(k_display_map, dim3((w + 63) / 64, (h + 3) / 4), dim3(RC_BLOCK), 0, s->cur,
+                           (const float2*)s->an.pt.p, (const float*)s->an.dist.p, w, h, which, key,
+                           (const uint8_t*)s->an.jet.p, d_bgr, bgr_step);
+    }
     RC_HIP(hipGetLastError());
     if (max_out) {
         unsigned int k = 0;
@@ -1227,8 +1236,11 @@ extern "C" int rcflow_streamline_positions_dev(rc_ctx* ctx, int stream, float* d
     const int w = s->an.w, h = s->an.h;
     if (!d_density || density_step < (size_t)w * 12) return RC_EINVAL;
     RC_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_positions, dim3((w + 63) / 64, (h + 3) / 4), dim3(RC_BLOCK), 0, s->cur, (const float2*)s->an.pt.p,
-                       w, h, d_density, density_step);
+    {
+        RcProfScope ps(ctx, s->cur, RC_K_DISPLAY, 0, 20. * w * h);
+        hipLaunchKernelGGL(k_positions, dim3((w + 63) / 64, (h + 3) / 4), dim3(RC_BLOCK), 0, s->cur, (const float2*)s->an.pt.p,
+                           w, h, d_density, density_step);
+    }
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
@@ -1239,8 +1251,11 @@ extern "C" int rcflow_hsv_to_bgr_dev(rc_ctx* ctx, int stream, const float* d_hsv
     if (!s) return RC_EINVAL;
     if (!d_hsv || !d_bgr || w <= 0 || h <= 0 || hsv_step < (size_t)w * 12 || bgr_step < (size_t)w * 12) return RC_EINVAL;
     RC_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_hsv_to_bgr, dim3((w + 63) / 64, (h + 3) / 4), dim3(RC_BLOCK), 0, s->cur, d_hsv, hsv_step, w, h,
-                       d_bgr, bgr_step);
+    {
+        RcProfScope ps(ctx, s->cur, RC_K_HSV2BGR, 0, 24. * w * h);
+        hipLaunchKernelGGL(k_hsv_to_bgr, dim3((w + 63) / 64, (h + 3) / 4), dim3(RC_BLOCK), 0, s->cur, d_hsv, hsv_step, w, h,
+                           d_bgr, bgr_step);
+    }
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
@@ -1424,7 +1439,10 @@ extern "C" int rcflow_resize_area_bgr_to_gray_dev(rc_ctx* ctx, int stream, const
         RC_HIP(hipMemcpy(d_ya, ya.data(), 4 * ny, hipMemcpyHostToDevice));
         a.xstart = d_xs; a.xsi = d_xi; a.xalpha = d_xa; a.ystart = d_ys; a.ysi = d_yi; a.yalpha = d_ya;
     }
-    hipLaunchKernelGGL(k_resize_area_bgr_to_gray, dim3((dw + 63) / 64, (dh + 3) / 4), dim3(RC_BLOCK), 0, s->cur, a);
+    {
+        RcProfScope ps(ctx, s->cur, RC_K_PREPROC, 0, 3. * sw * sh + 1. * dw * dh);
+        hipLaunchKernelGGL(k_resize_area_bgr_to_gray, dim3((dw + 63) / 64, (dh + 3) / 4), dim3(RC_BLOCK), 0, s->cur, a);
+    }
     RC_HIP(hipGetLastError());
     return RC_OK;
 }
@@ -1447,8 +1465,11 @@ extern "C" int rcflow_create_output_dev(rc_ctx* ctx, int stream, uint8_t* d_subf
         return RC_EINVAL;
     }
     RC_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_create_output, dim3((w + 63) / 64, (h + 3) / 4), dim3(RC_BLOCK), 0, s->cur, d_subframe_bgr, step,
-                       d_outmask, mask_step, w, h);
+    {
+        RcProfScope ps(ctx, s->cur, RC_K_OVERLAY, 0, 7. * w * h);
+        hipLaunchKernelGGL(k_create_output, dim3((w + 63) / 64, (h + 3) / 4), dim3(RC_BLOCK), 0, s->cur, d_subframe_bgr, step,
+                           d_outmask, mask_step, w, h);
+    }
     RC_HIP(hipGetLastError());
     return RC_OK;
 }

@@ -83,7 +83,117 @@ __global__ __launch_bounds__(256) void k_exact_polyexp(RcPolyArgs a) {
     }
 }
 
+// The same arithmetic for the radii the reference and the OpenCV samples use (15, 7, 5), organised for the
+// machine: 64 x 32 outputs per 256-thread block; vertical pass = one thread per (column, 8 rows) over a
+// register window of 8 + 2N rows (every input row is loaded once per block instead of once per tap),
+// results in three LDS planes; horizontal pass = one thread per (row, 4 pixels) over a register window of
+// 4 + 2N columns read as float4s, the six double accumulators of a pixel advanced in upstream's tap order
+// (the chains of different accumulators are independent, so plane by plane gives the same bits).
+#ifndef RC_EXP_WAVES
+#define RC_EXP_WAVES 2
+#endif
+template <int N>
+__global__ __launch_bounds__(256, RC_EXP_WAVES) void k_exact_polyexp_t(RcPolyArgs a) {
+    constexpr int TW = 64, TH = 32, NP = (N + 3) & ~3, CW = TW + 2 * NP, R = 8, NW = R + 2 * N;
+    constexpr int PX = 2, HW = PX + 2 * NP;                // PX pixels per item; floats under their taps (8-byte aligned reads)
+    __shared__ __align__(16) float rows[3][TH][CW];
+    const int tid = threadIdx.x, z = blockIdx.z;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const int w = a.w, h = a.h;
+    const int slot = (a.slot0 + z * a.zstep) % a.nslots;
+    const float* I = a.I + (size_t)slot * a.I_slot_stride;
+
+    for (int item = tid; item < CW * (TH / R); item += 256) {
+        const int lc = item % CW, grp = item / CW;
+        const int c = rc_clampi(tx0 - NP + lc, 0, w - 1), y0 = ty0 + grp * R;
+        float win[NW];
+#pragma unroll
+        for (int j = 0; j < NW; j++) win[j] = I[(size_t)rc_clampi(y0 - N + j, 0, h - 1) * w + c];
+#pragma unroll
+        for (int o = 0; o < R; o++) {
+            float t0 = win[o + N] * a.pk.g[0], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+                const float s0 = win[o + N - k], s1 = win[o + N + k];
+                const float p = s0 + s1;
+                t0 = t0 + a.pk.g[k] * p;
+                t1 = t1 + a.pk.xg[k] * (s1 - s0);
+                t2 = t2 + a.pk.xxg[k] * p;
+            }
+            rows[0][grp * R + o][lc] = t0; rows[1][grp * R + o][lc] = t1; rows[2][grp * R + o][lc] = t2;
+        }
+    }
+    __syncthreads();
+    float4* RA = a.RA + (size_t)slot * a.R_slot_stride;
+    float* RB = a.RB + (size_t)slot * a.R_slot_stride;
+    for (int item = tid; item < TH * (TW / PX); item += 256) {
+        const int gp = item % (TW / PX), ly = item / (TW / PX);
+        const int y = ty0 + ly, x0 = tx0 + PX * gp;
+        if (y >= h || x0 >= w) continue;
+        double b1[PX], b2[PX], b3[PX], b4[PX], b5[PX], b6[PX];
+        float v[HW];
+        // pixel p of the item sits at v[NP + p]; its taps at v[NP + p -+ k]
+#define RC_LOAD_PLANE(pl)                                                     \
+        _Pragma("unroll") for (int q = 0; q < HW / 2; q++) {                  \
+            const float2 t = *(const float2*)&rows[pl][ly][PX * gp + 2 * q];   \
+            v[2 * q] = t.x; v[2 * q + 1] = t.y;                               \
+        }
+        RC_LOAD_PLANE(0)
+#pragma unroll
+        for (int p = 0; p < PX; p++) {
+            const float* q0 = v + NP + p;
+            double s1 = q0[0] * a.pk.g[0], s2 = 0, s4 = 0;
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+                const double tg = q0[k] + q0[-k];
+                s1 += tg * a.pk.g[k];
+                s4 += tg * a.pk.xxg[k];
+                s2 += (q0[k] - q0[-k]) * a.pk.xg[k];
+            }
+            b1[p] = s1; b2[p] = s2; b4[p] = s4;
+        }
+        RC_LOAD_PLANE(1)
+#pragma unroll
+        for (int p = 0; p < PX; p++) {
+            const float* q1 = v + NP + p;
+            double s3 = q1[0] * a.pk.g[0], s6 = 0;
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+                s3 += (q1[k] + q1[-k]) * a.pk.g[k];
+                s6 += (q1[k] - q1[-k]) * a.pk.xg[k];
+            }
+            b3[p] = s3; b6[p] = s6;
+        }
+        RC_LOAD_PLANE(2)
+#pragma unroll
+        for (int p = 0; p < PX; p++) {
+            const float* q2 = v + NP + p;
+            double s5 = q2[0] * a.pk.g[0];
+#pragma unroll
+            for (int k = 1; k <= N; k++) s5 += (q2[k] + q2[-k]) * a.pk.g[k];
+            b5[p] = s5;
+        }
+#undef RC_LOAD_PLANE
+#pragma unroll
+        for (int p = 0; p < PX; p++) {
+            if (x0 + p >= w) break;
+            float4 ra;
+            ra.y = (float)(b2[p] * a.pk.ig11);
+            ra.x = (float)(b3[p] * a.pk.ig11);
+            ra.w = (float)(b1[p] * a.pk.ig03 + b4[p] * a.pk.ig33);
+            ra.z = (float)(b1[p] * a.pk.ig03 + b5[p] * a.pk.ig33);
+            const size_t o = (size_t)y * w + x0 + p;
+            RA[o] = ra;
+            RB[o] = (float)(b6[p] * a.pk.ig55);
+        }
+    }
+}
+
 void rc_launch_exact_polyexp(const RcPolyArgs& a, int frames, hipStream_t s) {
+    dim3 tgrid((a.w + 63) / 64, (a.h + 31) / 32, frames);
+    if (a.pk.n == 15 && !a.no_fast_u8) { hipLaunchKernelGGL(k_exact_polyexp_t<15>, tgrid, dim3(256), 0, s, a); return; }
+    if (a.pk.n == 7 && !a.no_fast_u8) { hipLaunchKernelGGL(k_exact_polyexp_t<7>, tgrid, dim3(256), 0, s, a); return; }
+    if (a.pk.n == 5 && !a.no_fast_u8) { hipLaunchKernelGGL(k_exact_polyexp_t<5>, tgrid, dim3(256), 0, s, a); return; }
     const size_t lds = sizeof(float) * 3 * RC_EX_TH * (RC_EX_TW + 2 * a.pk.n);
     dim3 grid((a.w + RC_EX_TW - 1) / RC_EX_TW, (a.h + RC_EX_TH - 1) / RC_EX_TH, frames);
     hipLaunchKernelGGL(k_exact_polyexp, grid, dim3(256), lds, s, a);

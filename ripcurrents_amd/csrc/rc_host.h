@@ -54,6 +54,13 @@ struct RcSlot {
     RcBuf FA[RC_MAX_LEVELS], FB[RC_MAX_LEVELS];
     RcBuf stage_u8, stage_flow, stage_f32[4];
     RcBuf exM, exV;            // option "exact": matrix planes and window column sums
+    // host-pointer frame loop (rcflow_push_frame_u8): two page-locked staging frames, an event per frame that
+    // fires when its upload has left the staging buffer, two device frames (stage_u8) and the resident flow
+    void* pin[2] = {nullptr, nullptr};
+    size_t pin_bytes = 0;
+    hipEvent_t pin_free[2] = {nullptr, nullptr};
+    int pin_i = 0;
+    int flow_w = 0, flow_h = 0;   // size of the flow field resident in stage_flow (0: none yet)
     RcBuf lk;                  // sparse PyrLK pyramids + derivatives (lk_kernels.hip)
     RcBuf area_tab;            // INTER_AREA decimation tables
     int primed = 0, cur_slot = 0;
@@ -88,6 +95,7 @@ struct rc_ctx {
     int hist_blocks = 0;       // option "hist_blocks": cap on histogram blocks per launch (0 = default)
     int fuse_pyr = 1;         // scale-0 expansion also writes pyramid scales 1 and 2 (exact 2:1 / 4:1 sizes)
     int ablate = 0;
+    void* comm = nullptr;      // RcComm (comm_rccl.hip): the histogram all-reduce over RCCL
     void* stamps = nullptr;
     int prof_on = 0;
     std::vector<RcProfRec> prof_pending;
@@ -97,7 +105,8 @@ struct rc_ctx {
 };
 
 enum { RC_K_PYR = 0, RC_K_POLY = 1, RC_K_ITER = 2, RC_K_HIST = 3, RC_K_THRESH = 4, RC_K_CLASSIFY = 5,
-       RC_K_ADVECT_FIELD = 6, RC_K_ADVECT_POINTS = 7, RC_K_POSTOP = 8, RC_K_COLOR = 9, RC_K_ITER2 = 10, RC_K_KINDS = 11 };
+       RC_K_ADVECT_FIELD = 6, RC_K_ADVECT_POINTS = 7, RC_K_POSTOP = 8, RC_K_COLOR = 9, RC_K_ITER2 = 10,
+       RC_K_PREPROC = 11, RC_K_EDGES = 12, RC_K_DISPLAY = 13, RC_K_HSV2BGR = 14, RC_K_OVERLAY = 15, RC_K_KINDS = 16 };
 
 void rc_set_error(const char* fmt, ...);
 int rc_buf_ensure(RcBuf& b, size_t bytes);

@@ -73,7 +73,20 @@ RcProfScope::~RcProfScope() {
 
 static const char* kKindNames[RC_K_KINDS] = {"pyr_level", "polyexp", "flow_iter", "polar_hist",
                                              "thresholds", "classify_accumulate", "advect_field",
-                                             "advect_points", "flow_postop", "flow_color", "flow_iter_x2"};
+                                             "advect_points", "flow_postop", "flow_color", "flow_iter_x2",
+                                             "frame_preproc", "create_edges", "streamline_display", "hsv_to_bgr",
+                                             "create_output"};
+// The reference's wall-clock buckets (ripcurrents.cpp:103-109, sampled at :205,223,293,314,411,483, printed at
+// :518-524) and the kernels that do each bucket's work here.  time_polar has no kernel of its own: the
+// cartToPolar of :305-309 is fused into the histogram and classification kernels; classify_accumulate spans
+// :376-439 (the reference samples time_threshold at :411, inside it) and is booked under "threshold";
+// time_codec (video decode) is host I/O outside this library.
+static const int kBucketOfKind[RC_K_KINDS] = {
+    /* pyr_level */ 0, /* polyexp */ 0, /* flow_iter */ 0, /* polar_hist */ 2, /* thresholds */ 2,
+    /* classify_accumulate */ 2, /* advect_field */ 6, /* advect_points */ 6, /* flow_postop */ 0, /* flow_color */ 2,
+    /* flow_iter_x2 */ 0, /* frame_preproc */ 0, /* create_edges */ 4, /* streamline_display */ 6, /* hsv_to_bgr */ 2,
+    /* create_output */ 3};
+static const char* kBucketNames[RC_PROFILE_BUCKETS] = {"farneback", "polar", "threshold", "overlay", "erosion", "codec", "stream"};
 static char g_names[RC_K_KINDS * RC_MAX_LEVELS][40];
 
 static void prof_resolve(rc_ctx* ctx) {
@@ -133,6 +146,18 @@ extern "C" int rcflow_profile_read(rc_ctx* ctx, int cap, const char** names, int
     return n;
 }
 
+extern "C" int rcflow_profile_read_buckets(rc_ctx* ctx, const char** names, double* ms) {
+    if (!ctx) return RC_EINVAL;
+    prof_resolve(ctx);
+    double b[RC_PROFILE_BUCKETS] = {0};
+    for (size_t id = 0; id < ctx->prof_ms.size(); id++) b[kBucketOfKind[id / RC_MAX_LEVELS]] += ctx->prof_ms[id];
+    for (int i = 0; i < RC_PROFILE_BUCKETS; i++) {
+        if (names) names[i] = kBucketNames[i];
+        if (ms) ms[i] = b[i];
+    }
+    return RC_PROFILE_BUCKETS;
+}
+
 // ---------------------------------------------------------------------------- lifetime
 extern "C" int rcflow_create(rc_ctx** out, int device, int max_w, int max_h, int max_streams) {
     if (!out || max_w <= 0 || max_h <= 0 || max_streams <= 0 || max_streams > 256) {
@@ -181,6 +206,12 @@ static void slot_free(RcSlot& s) {
     rc_batch_graph_drop(s);
     rc_buf_free(s.stage_u8); rc_buf_free(s.stage_flow); rc_buf_free(s.lk); rc_buf_free(s.area_tab);
     rc_buf_free(s.exM); rc_buf_free(s.exV);
+    for (int i = 0; i < 2; i++) {
+        if (s.pin[i]) (void)hipHostFree(s.pin[i]);
+        if (s.pin_free[i]) (void)hipEventDestroy(s.pin_free[i]);
+        s.pin[i] = nullptr; s.pin_free[i] = nullptr;
+    }
+    s.pin_bytes = 0;
     for (auto& b : s.stage_f32) rc_buf_free(b);
     rc_buf_free(s.an.hist); rc_buf_free(s.an.hist_part); rc_buf_free(s.an.thr); rc_buf_free(s.an.acc);
     rc_buf_free(s.an.pt); rc_buf_free(s.an.dist); rc_buf_free(s.an.scratch); rc_buf_free(s.an.jet);
@@ -194,6 +225,7 @@ extern "C" void rcflow_destroy(rc_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    (void)rcflow_comm_destroy(ctx);
     prof_resolve(ctx);
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->slots) {
@@ -827,6 +859,7 @@ extern "C" int rcflow_stream_reset(rc_ctx* ctx, int stream) {
     if (!s) return RC_EINVAL;
     s->primed = 0;
     s->cur_slot = 0;
+    s->flow_w = s->flow_h = 0;
     return RC_OK;
 }
 
@@ -852,6 +885,73 @@ extern "C" int rcflow_push_frame_dev(rc_ctx* ctx, int stream, const uint8_t* d_f
     if ((rc = expand_frames(ctx, *s, d_frame, 0, step, 1, nxt))) return rc;
     if ((rc = compute_flows(ctx, *s, 1, s->cur_slot, d_flow, 0, flow_step))) return rc;
     s->cur_slot = nxt;
+    return RC_OK;
+}
+
+// The reference's frame loop with HOST frames (ripcurrents.cpp:198-221: video.read -> resize -> cvtColor ->
+// copyTo(UMat) -> calcOpticalFlowFarneback -> copyTo(u_f2)): the frame goes through one of two page-locked
+// staging buffers and is uploaded asynchronously; the flow field stays on the device for the analysis calls
+// (rcflow_stream_flow_ptr) and only crosses PCIe when the host asks for it (rcflow_stream_flow_read).  The call
+// returns once the frame is in the staging buffer -- the upload of frame t and the kernels of frame t run
+// while the host decodes frame t + 1.  Returns 1 when the call only primed the stream (no flow yet).
+extern "C" int rcflow_push_frame_u8(rc_ctx* ctx, int stream, const uint8_t* frame, size_t step, int w, int h,
+                                    const rc_farneback_params* p) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !frame || w <= 0 || h <= 0 || step < (size_t)w) { if (s) rc_set_error("bad frame arguments"); return RC_EINVAL; }
+    if (w > ctx->max_w || h > ctx->max_h) { rc_set_error("frame %dx%d exceeds the context's %dx%d", w, h, ctx->max_w, ctx->max_h); return RC_ESIZE; }
+    RC_HIP(hipSetDevice(ctx->device));
+    const size_t fb = (size_t)w * h;
+    int rc;
+    if (s->pin_bytes < fb) {
+        RC_HIP(hipStreamSynchronize(s->cur));
+        for (int i = 0; i < 2; i++) {
+            if (s->pin[i]) (void)hipHostFree(s->pin[i]);
+            s->pin[i] = nullptr;
+            if (hipHostMalloc(&s->pin[i], fb, hipHostMallocDefault) != hipSuccess) { rc_set_error("hipHostMalloc(%zu) failed", fb); s->pin_bytes = 0; return RC_ENOMEM; }
+            if (!s->pin_free[i]) RC_HIP(hipEventCreateWithFlags(&s->pin_free[i], hipEventDisableTiming));
+            RC_HIP(hipEventRecord(s->pin_free[i], s->cur));
+        }
+        s->pin_bytes = fb;
+    }
+    if ((rc = rc_buf_ensure(s->stage_u8, 2 * fb))) return rc;
+    if ((rc = rc_buf_ensure(s->stage_flow, fb * 8))) return rc;
+    const int i = s->pin_i;
+    RC_HIP(hipEventSynchronize(s->pin_free[i]));              // the upload that last used this staging buffer has left it
+    uint8_t* dst = (uint8_t*)s->pin[i];
+    if (step == (size_t)w) memcpy(dst, frame, fb);
+    else for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * w, frame + (size_t)y * step, w);
+    uint8_t* d_frame = (uint8_t*)s->stage_u8.p + (size_t)i * fb;
+    RC_HIP(hipMemcpyAsync(d_frame, dst, fb, hipMemcpyHostToDevice, s->cur));
+    RC_HIP(hipEventRecord(s->pin_free[i], s->cur));
+    s->pin_i = i ^ 1;
+    rc = rcflow_push_frame_dev(ctx, stream, d_frame, w, w, h, (float*)s->stage_flow.p, (size_t)w * 8, p);
+    if (rc == RC_OK) { s->flow_w = w; s->flow_h = h; }
+    else if (rc == 1) { s->flow_w = s->flow_h = 0; }
+    return rc;
+}
+
+// Device address of the flow field the last rcflow_push_frame_u8 produced (w x h float2, dense rows), for the
+// analysis entry points; valid until the next push on the slot.
+extern "C" int rcflow_stream_flow_ptr(rc_ctx* ctx, int stream, float** d_flow, int* w, int* h) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !d_flow) return RC_EINVAL;
+    if (!s->flow_w) { rc_set_error("no flow field yet: the stream has only been primed"); return RC_ESTATE; }
+    *d_flow = (float*)s->stage_flow.p;
+    if (w) *w = s->flow_w;
+    if (h) *h = s->flow_h;
+    return RC_OK;
+}
+
+// Copies that flow field to the host (CV_32FC2 layout, byte step) and waits for it.
+extern "C" int rcflow_stream_flow_read(rc_ctx* ctx, int stream, float* flow, size_t flow_step) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !flow) return RC_EINVAL;
+    if (!s->flow_w) { rc_set_error("no flow field yet: the stream has only been primed"); return RC_ESTATE; }
+    if (flow_step < (size_t)s->flow_w * 8) { rc_set_error("row step smaller than a row"); return RC_EINVAL; }
+    RC_HIP(hipSetDevice(ctx->device));
+    RC_HIP(hipMemcpy2DAsync(flow, flow_step, s->stage_flow.p, (size_t)s->flow_w * 8, (size_t)s->flow_w * 8, s->flow_h,
+                            hipMemcpyDeviceToHost, s->cur));
+    RC_HIP(hipStreamSynchronize(s->cur));
     return RC_OK;
 }
 

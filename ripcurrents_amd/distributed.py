@@ -8,8 +8,10 @@ the cumulative flow-histogram counters -- hist[50] | hist2d[36*50] | histsum | h
 (UPPER, UPPER2d, prop_above_upper) from the same integers.  Integer sums commute, so the
 result equals the reference's histogram after processing all segments in any order.
 
-torch.distributed is the transport: backend "nccl" is RCCL over xGMI on ROCm; "gloo" is
-used by the CPU tests.
+Two transports for that one sum: torch.distributed (backend "nccl" is RCCL over xGMI on ROCm; "gloo" is
+used by the CPU tests), and the library's own C-ABI collective (rcflow_comm_init / rcflow_allreduce_hist,
+librccl opened directly) -- what a C++ host like the reference's uses; init_comm() below sets it up for a
+Python host, with torch.distributed only as the out-of-band channel that carries the 128-byte RCCL id.
 """
 import torch
 import torch.distributed as dist
@@ -54,6 +56,20 @@ def allreduce_hist_words_async(words, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True)
     return PendingHistSum(work, g)
+
+
+def init_comm(ctx, group=None):
+    """Joins the context's C-ABI communicator with the ranks of the torch.distributed group: rank 0
+    creates the RCCL unique id, torch.distributed broadcasts its 128 bytes (any backend), every rank calls
+    rcflow_comm_init.  Without an initialised process group the world is one rank (identity collective)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        ctx.comm_init(0, 1)
+        return 0, 1
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [ctx.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    ctx.comm_init(rank, world, box[0])
+    return rank, world
 
 
 def split_hist_words(words):

@@ -132,6 +132,49 @@ int main() {
         REQUIRE(!pipe.pushFrame(ma, mfl, 0.5, 2, 10, 3, 15, 1.2, 256));      // other parameters: primes again
     }
 
+    // the asynchronous host loop: frames from host memory through the page-locked double buffer, the flow field
+    // never leaves the device, the analysis reads the resident field; and the reference's timing buckets
+    {
+        std::vector<uint8_t> fr[4];
+        for (int t = 0; t < 4; t++) make_frame(fr[t], 20 + t);
+        rc::Mat none;
+        int h1[RC_HIST_BINS], hs1 = 0, h2d1[RC_HIST_DIRECTIONS][RC_HIST_BINS], hs2d1[RC_HIST_DIRECTIONS];
+        int h2[RC_HIST_BINS], hs2 = 0, h2d2[RC_HIST_DIRECTIONS][RC_HIST_BINS], hs2d2[RC_HIST_DIRECTIONS];
+        float U, U2[RC_HIST_DIRECTIONS], P[RC_HIST_DIRECTIONS];
+        REQUIRE(rcflow_analysis_reset(pipe.context(), 0, XDIM, YDIM) == 0);
+        REQUIRE(rcflow_stream_reset(pipe.context(), 0) == 0);
+        REQUIRE(rcflow_profile_reset(pipe.context()) == 0 && rcflow_profile_enable(pipe.context(), 1) == 0);
+        for (int t = 0; t < 4; t++) {
+            rc::Mat m(YDIM, XDIM, 1, 1, fr[t].data());
+            if (pipe.pushFrame(m, none, 0.5, 2, 3, 2, 15, 1.2, 0)) pipe.create_histogram(h1, hs1, h2d1, hs2d1, U, U2, P);
+        }
+        REQUIRE(rcflow_profile_enable(pipe.context(), 0) == 0);
+        const char* names[RC_PROFILE_BUCKETS];
+        double ms[RC_PROFILE_BUCKETS];
+        REQUIRE(rcflow_profile_read_buckets(pipe.context(), names, ms) == RC_PROFILE_BUCKETS);
+        REQUIRE(!strcmp(names[0], "farneback") && !strcmp(names[2], "threshold") && !strcmp(names[6], "stream"));
+        REQUIRE(ms[0] > 0 && ms[2] > 0 && ms[1] == 0 && ms[5] == 0);
+        printf("Time spent on farneback: %f ms\nTime spent on thresholds: %f ms\n", ms[0], ms[2]);   // ripcurrents.cpp:518-520
+        REQUIRE(rcflow_analysis_reset(pipe.context(), 0, XDIM, YDIM) == 0);
+        for (int t = 0; t < 3; t++) {
+            rc::Mat a(YDIM, XDIM, 1, 1, fr[t].data()), b(YDIM, XDIM, 1, 1, fr[t + 1].data());
+            pipe.calcOpticalFlowFarneback(a, b, none, 0.5, 2, 3, 2, 15, 1.2, 0);
+            pipe.create_histogram(h2, hs2, h2d2, hs2d2, U, U2, P);
+        }
+        REQUIRE(hs1 == hs2 && hs1 > 0 && memcmp(h2d1, h2d2, sizeof(h2d1)) == 0);
+        // the collective behind the C ABI: a world of one rank is the identity (no RCCL involved)
+        REQUIRE(rcflow_comm_init(pipe.context(), nullptr, 0, 1) == 0);
+        REQUIRE(rcflow_allreduce_hist(pipe.context(), 0, nullptr) == 0 && rcflow_allreduce_hist_join(pipe.context(), 0) == 0);
+        int32_t* d_sum = nullptr;
+        REQUIRE(rcflow_allreduce_hist_result(pipe.context(), &d_sum) == 0 && d_sum);
+        REQUIRE(rcflow_thresholds_words_dev(pipe.context(), 0, d_sum) == 0 && rcflow_sync(pipe.context(), 0) == 0);
+        std::vector<int32_t> words(RC_HIST_WORDS);
+        REQUIRE(hipMemcpy(words.data(), d_sum, RC_HIST_WORDS * 4, hipMemcpyDeviceToHost) == hipSuccess);
+        REQUIRE(words[RC_HIST_BINS + RC_HIST_DIRECTIONS * RC_HIST_BINS] == hs2);
+        REQUIRE(rcflow_comm_destroy(pipe.context()) == 0);
+        REQUIRE(rcflow_allreduce_hist(pipe.context(), 0, nullptr) == RC_ECOMM);
+    }
+
     bool threw = false;
     try {
         rc::Mat prev(YDIM, XDIM, 1, 1, f2.data()), bad;

@@ -639,3 +639,47 @@ def test_display_against_committed_golden_fixture(ctx):
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "display_64x48.npz"))
     assert np.array_equal(ctx.jet_lut(), g["jet"])
     assert np.array_equal(ctx.hsv_to_bgr(g["hsv"]).cpu().numpy(), g["bgr"])
+
+
+def test_host_frame_loop_pinned_double_buffer(ctx):
+    """rcflow_push_frame_u8: frames from host memory through the page-locked double buffer; the flow stays on
+    the device (the analysis reads it there) and equals the device-pointer loop bit for bit."""
+    from ripcurrents_amd import RcflowError
+    w, h, T = 333, 251, 6
+    clip = synth.surf_clip(w, h, T, seed=12)
+    p = dict(pyr_scale=0.5, levels=2, winsize=3, iterations=2, poly_n=15, poly_sigma=1.2, flags=0)
+    d = torch.as_tensor(clip).cuda()
+    ref = ctx.farneback_clip(d, **p).cpu().numpy()
+    ctx.stream_reset()
+    with pytest.raises(RcflowError):
+        ctx.stream_flow_read(w, h)                      # nothing resident yet
+    padded = np.zeros((T, h, w + 19), np.uint8)         # a cv::Mat-style row step
+    padded[:, :, :w] = clip
+    assert ctx.push_frame_host(padded[0, :, :w], **p) is None
+    for t in range(1, T):
+        f = ctx.push_frame_host(padded[t, :, :w], **p)
+        assert f is not None and f.shape == (h, w, 2)
+        if t in (1, 3, 5):
+            assert np.array_equal(ctx.stream_flow_read(w, h), ref[t - 1])
+        else:
+            ctx.sync()
+            assert np.array_equal(f.cpu().numpy(), ref[t - 1])
+    ctx.stream_reset()
+
+
+def test_profile_buckets_carry_the_reference_names(ctx):
+    """rcflow_profile_read_buckets: GPU time under the names of ripcurrents.cpp:103-109 / :518-524."""
+    w, h = 320, 240
+    clip = torch.as_tensor(synth.surf_clip(w, h, 3, seed=2)).cuda()
+    ctx.analysis_reset(w, h)
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    flow = ctx.calcOpticalFlowFarneback(clip[0], clip[1], None)
+    ctx.streamline_field(flow, 2.0, 1)
+    ctx.create_histogram(flow)
+    ctx.create_flow_accumulate(flow, 31)
+    ctx.profile_enable(False)
+    b = ctx.profile_read_buckets()
+    assert list(b) == ["farneback", "polar", "threshold", "overlay", "erosion", "codec", "stream"]
+    assert b["farneback"] > 0 and b["threshold"] > 0 and b["stream"] > 0 and b["polar"] == 0 and b["codec"] == 0
+    ctx.profile_reset()

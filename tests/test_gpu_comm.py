@@ -1,0 +1,78 @@
+"""GPU tier: the C-ABI collective (rcflow_comm_init / rcflow_allreduce_hist) on the one GPU
+of the test box -- a world of one rank is the identity (RCCL refuses two ranks on one device; the N-rank sum is
+covered on CPU by tests/test_distributed_gloo.py and on hardware by the driver's SCALE run with
+`bench.py --collective rccl`) -- and the int32 overflow guard of the histogram counters."""
+import numpy as np
+import pytest
+import torch
+
+from ripcurrents_amd import RcflowError, synth
+from ripcurrents_amd.api import Context, HistState
+from ripcurrents_amd.distributed import init_comm
+
+pytestmark = pytest.mark.gpu
+
+
+def test_collective_needs_init(ctx):
+    ctx.analysis_reset(64, 48)
+    ctx.comm_destroy()
+    with pytest.raises(RcflowError) as e:
+        ctx.allreduce_hist()
+    assert e.value.code == -7          # RC_ECOMM
+    with pytest.raises(RcflowError) as e:
+        ctx.comm_init(2, 2, b"\0" * 128)
+    assert e.value.code == -1
+
+
+def test_world_of_one_is_the_identity_and_feeds_the_thresholds(ctx, orc):
+    w, h = 320, 240
+    rng = np.random.RandomState(3)
+    flow = (rng.randn(h, w, 2) * 0.8).astype(np.float32)
+    ctx.analysis_reset(w, h)
+    assert init_comm(ctx) == (0, 1)
+    ctx.histogram_accumulate(flow)
+    g = ctx.allreduce_hist()
+    ctx.allreduce_hist_join()
+    ctx.thresholds_from_words(g)
+    st = ctx.histogram_read()
+    ctx.sync()
+    assert np.array_equal(g.cpu().numpy(), ctx.histogram_words().cpu().numpy())
+    ost = orc.HistState()
+    orc.create_histogram(orc.flow_to_polar(flow), ost)
+    assert st.UPPER == ost.UPPER and np.array_equal(st.UPPER2d, ost.UPPER2d)
+    assert np.array_equal(st.prop_above_upper, ost.prop_above_upper, equal_nan=True)
+    # a second collective while the first result is still referenced, into a caller's buffer
+    out = torch.zeros(g.numel(), dtype=torch.int32, device="cuda")
+    ctx.histogram_accumulate(flow)
+    ctx.allreduce_hist(out=out)
+    ctx.allreduce_hist_join()
+    ctx.sync()
+    assert np.array_equal(out.cpu().numpy(), 2 * g.cpu().numpy())
+    ctx.comm_destroy()
+
+
+def test_unique_id_comes_from_librccl(ctx):
+    a, b = ctx.comm_unique_id(), ctx.comm_unique_id()
+    assert len(a) == 128 and a != b
+
+
+def test_histogram_refuses_to_wrap_int32(ctx):
+    """ripcurrents.cpp:147-150 keeps `int` counters and never resets them: they wrap after 2^31 / (w h) frames.
+    The library counts the pixels it was given since the last reset and refuses the call that could carry
+    histsum past INT32_MAX; rcflow_histogram_reset_dev starts a new segment."""
+    w, h, T = 1920, 1080, 64
+    flows = torch.zeros((T, h, w, 2), dtype=torch.float32, device="cuda")      # every pixel lands in bin 0
+    ctx.analysis_reset(w, h)
+    calls = (2 ** 31 - 1) // (w * h * T)
+    for _ in range(calls):
+        ctx.histogram_accumulate_clip(flows)
+    st = ctx.histogram_read()
+    assert st.histsum == calls * T * w * h and st.histsum > 2.1e9          # exact, not wrapped
+    with pytest.raises(RcflowError) as e:
+        ctx.histogram_accumulate_clip(flows)
+    assert e.value.code == -6          # RC_ESTATE
+    assert ctx.histogram_read().histsum == st.histsum                      # the refused call counted nothing
+    ctx.histogram_reset()
+    ctx.histogram_accumulate_clip(flows[:2])
+    assert ctx.histogram_read().histsum == 2 * w * h
+    ctx.analysis_reset(64, 48)

@@ -619,6 +619,35 @@ def test_lockstep_stream_batch_matches_per_stream(ctx, use_graph):
     ctx.batch_reset()
 
 
+def test_config5_sixteen_1080p_streams_hipgraph(ctx, orc):
+    """BASELINE config 5 at its stated size: 16 independent 1080p streams advanced in lockstep, hipGraph replay
+    in steady state.  Streams 0, 7 and 15 are checked against separate two-image calls (bit-identical) and one of
+    them against the oracle (8(d) metric)."""
+    S, T, w, h = 16, 5, 1920, 1080
+    base = synth.surf_clip(w, h, T + 2, seed=55)
+    # 16 different streams from one clip: shifted in time and mirrored / transposed-free variations
+    clips = np.stack([np.roll(base[(s % 3):(s % 3) + T], shift=17 * s, axis=2)[:, ::(-1 if s & 1 else 1)].copy() for s in range(S)])
+    d = torch.as_tensor(clips).cuda()
+    frames = torch.empty((S, h, w), dtype=torch.uint8, device="cuda")
+    flows = torch.empty((S, h, w, 2), dtype=torch.float32, device="cuda")
+    ctx.batch_reset()
+    got = {}
+    for t in range(T):
+        frames.copy_(d[:, t])
+        r = ctx.push_batch(frames, flows, use_graph=True, **RC215)
+        if r is not None:
+            ctx.sync()
+            got[t] = {s: r[s].cpu().numpy().copy() for s in (0, 7, 15)}
+    assert sorted(got) == [1, 2, 3, 4]          # eager, capture, replay, replay
+    for s in (0, 7, 15):
+        for t in (1, 4):
+            ref = ctx.calcOpticalFlowFarneback(clips[s, t - 1], clips[s, t], None, **RC215)
+            assert np.array_equal(got[t][s], ref), (s, t)
+    ref, dets = _oracle_diag(orc, clips[7, 3], clips[7, 4], RC215, nthreads=8)
+    assert_conditioned("C5 stream 7 of 16 x 1080p (graph replay)", got[4][7], ref, *dets)
+    ctx.batch_reset()
+
+
 def test_two_threads_on_two_stream_slots(ctx):
     """include/rcflow.h: a context is thread-safe across distinct stream indices.  Two host threads,
     one slot each, different sizes and parameter sets, interleaved calls: same bits as one thread."""
