@@ -19,6 +19,7 @@ def main():
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
             short = name.split("(")[0].replace("void ", "")
+            short = short.split("::")[-1] if "::k_" in short else short
             if not short.startswith("k_"):
                 short = "(torch) " + short[:60]
             key = (short, "%sx%sx%s" % (r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"]),
