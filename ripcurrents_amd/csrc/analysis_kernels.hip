@@ -168,6 +168,153 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist(const float* flow0, siz
     }
 }
 
+// ---- second form of the histogram kernel (the one that runs; k_polar_hist above is kept behind option
+// "ablate" bit RC_ABL_HIST_V1 for A/B runs).  Two changes, same counts:
+//  * the key.  ripcurrents.cpp:305-309 + ripcurrents_module.cpp:97-100 cost a correctly rounded sqrt and two IEEE
+//    divisions per pixel (min/max inside fastAtan2, and (angle*36)/360).  Here the magnitude is s*rsq(s) and the
+//    quotients are products with v_rcp_f32 / a constant -- each within a few ulps of the exact value -- and a pixel
+//    whose scaled magnitude mag*20 or scaled angle lands within 1e-4 of an integer (where a few ulps could change
+//    the floor), or is not finite, takes the exact path.  1e-4 is >= 5x the worst-case gap between the two
+//    evaluations (relative 4e-7 on values below 51 and 36.0002), so the floors agree for every other pixel; about 4
+//    pixels in 10 000 take the exact path.  tests: test_histogram_key_on_bin_edges, test_fast_atan_and_histogram_exact.
+//  * the aggregation.  A lane takes a 2-pixel-wide column of 4 rows: 8 pixels that mostly share one key.  The lane
+//    counts how many of its 8 keys equal its first one, adds the rest (rare) singly, and only the (key, count) pair
+//    goes through the wave-level step: the first lane's key is broadcast, the counts of all lanes holding it are
+//    summed with DPP / permute steps and added by one LDS atomic; lanes holding another key add their own pair.
+//    One scalar round per 8 pixels instead of one per pixel.
+__device__ __forceinline__ int rc_hist_key_fast(float2 f, bool& exact_needed) {
+    const float s = f.x * f.x + f.y * f.y;
+    const float m = s > 0.f ? s * __builtin_amdgcn_rsqf(s) : s;      // s = 0, NaN: m = s
+    const float t = m * (float)RC_HIST_RESOLUTION;
+    const float rt = rintf(t);
+    // direction: OpenCV's polynomial on lo / hi with the quotient as a product
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float ax = fabsf(f.x), ay = fabsf(f.y);
+    const bool xmajor = ax >= ay;
+    const float lo = xmajor ? ay : ax, hi = xmajor ? ax : ay;
+    const float c = lo * __builtin_amdgcn_rcpf(hi + (float)DBL_EPSILON);
+    const float c2 = c * c;
+    float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    if (!xmajor) a = 90.f - a;
+    if (f.x < 0) a = 180.f - a;
+    if (f.y < 0) a = 360.f - a;
+    const float u = a * ((float)RC_HIST_DIRECTIONS / 360.f);
+    const float ru = rintf(u);
+    // (comparisons written so that a NaN fails them)
+    const bool mag_ok = fabsf(t - rt) > 1e-4f && t < 1e6f;
+    const bool dir_ok = fabsf(u - ru) > 1e-4f;
+    const int bin = (int)t;                                          // t < 1e6 where it is used
+    const bool counted = bin < RC_HIST_BINS;                         // t >= 0 always
+    exact_needed = !mag_ok || (counted && !dir_ok);
+    int d = (int)u;
+    if (d >= RC_HIST_DIRECTIONS || d < 0) d = 0;
+    return counted ? d * RC_HIST_BINS + bin : -1;
+}
+
+__device__ __forceinline__ int rc_wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(RC_BLOCK) void k_polar_hist_rows(const float* flow0, size_t frame_stride, size_t step,
+                                                              int w, int h, int* parts) {
+    __shared__ int lh[RC_HIST_DIRECTIONS * RC_HIST_BINS];
+    const float* flow = (const float*)((const char*)flow0 + (size_t)blockIdx.y * frame_stride);
+    for (int i = threadIdx.x; i < RC_HIST_DIRECTIONS * RC_HIST_BINS; i += RC_BLOCK) lh[i] = 0;
+    __syncthreads();
+    constexpr int NR = 4;                       // rows per item
+    const int w2 = (w + 1) >> 1, hg = (h + NR - 1) / NR;
+    const int total = w2 * hg;
+    const int span = (int)gridDim.x * RC_BLOCK;
+    const int rounds = (total + span - 1) / span;
+    const int i0 = (int)blockIdx.x * RC_BLOCK + threadIdx.x;
+    int gg = i0 / w2, xx = i0 - gg * w2;        // (row group, pair in row), advanced by span per round
+    const int dg = span / w2, dx = span - dg * w2;
+    const int lane = threadIdx.x & 63;
+    float4 vn[NR];
+    int nn[NR];
+    auto load_item = [&](int it) {
+        const int g = gg, x = xx * 2;
+        gg += dg; xx += dx;
+        if (xx >= w2) { xx -= w2; gg++; }
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            nn[r] = 0;
+            vn[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int y = g * NR + r;
+            if (it < rounds && g < hg && y < h) {
+                const float2* p = rc_row2(flow, step, y) + x;
+                if (x + 1 < w && (((size_t)p) & 15) == 0) {
+                    typedef float rc_f4 __attribute__((ext_vector_type(4)));
+                    const rc_f4 t = __builtin_nontemporal_load((const rc_f4*)p);
+                    vn[r] = make_float4(t.x, t.y, t.z, t.w);
+                    nn[r] = 2;
+                } else {
+                    const float2 a0 = p[0];
+                    const float2 a1 = x + 1 < w ? p[1] : make_float2(0.f, 0.f);
+                    vn[r] = make_float4(a0.x, a0.y, a1.x, a1.y);
+                    nn[r] = x + 1 < w ? 2 : 1;
+                }
+            }
+        }
+    };
+    load_item(0);
+    for (int it = 0; it < rounds; it++) {        // block-uniform trip count: the wave steps below see whole waves
+        float4 v[NR];
+        int nv[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) { v[r] = vn[r]; nv[r] = nn[r]; }
+        if (it + 1 < rounds) load_item(it + 1);
+        int k[2 * NR];
+        bool redo = false;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            bool e0, e1;
+            const int k0 = rc_hist_key_fast(make_float2(v[r].x, v[r].y), e0);
+            const int k1 = rc_hist_key_fast(make_float2(v[r].z, v[r].w), e1);
+            k[2 * r] = nv[r] >= 1 ? k0 : -1;
+            k[2 * r + 1] = nv[r] >= 2 ? k1 : -1;
+            redo |= (nv[r] >= 1 && e0) || (nv[r] >= 2 && e1);
+        }
+        if (redo) {                              // a pixel near a bin / direction edge: the reference's own arithmetic
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                if (nv[r] >= 1) k[2 * r] = rc_hist_key(make_float2(v[r].x, v[r].y));
+                if (nv[r] >= 2) k[2 * r + 1] = rc_hist_key(make_float2(v[r].z, v[r].w));
+            }
+        }
+        // lane level: the first key and its multiplicity; other keys singly
+        const int A = k[0];
+        int cnt = 1;
+#pragma unroll
+        for (int i = 1; i < 2 * NR; i++) {
+            if (k[i] == A) cnt++;
+            else if (k[i] >= 0) atomicAdd(&lh[k[i]], 1);
+        }
+        // wave level: everything that shares the first active lane's key goes in one atomic
+        const unsigned long long todo = __ballot(A >= 0);
+        if (todo) {
+            const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+            const int kL = __builtin_amdgcn_readlane(A, leader);
+            const bool same = A == kL;
+            const int sum = rc_wave_sum(same ? cnt : 0);
+            if (lane == leader) atomicAdd(&lh[kL], sum);
+            else if (A >= 0 && !same) atomicAdd(&lh[A], cnt);
+        }
+    }
+    __syncthreads();
+    int* part = parts + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) % RC_HIST_COPIES) *
+                            (RC_HIST_DIRECTIONS * RC_HIST_BINS);
+    for (int i = threadIdx.x; i < RC_HIST_DIRECTIONS * RC_HIST_BINS; i += RC_BLOCK) {
+        int v = lh[i];
+        if (v) atomicAdd(&part[i], v);
+    }
+}
+
 // Folds (and clears) the partial tables into the slot's cumulative counters
 // words = hist[50] | hist2d[1800] | histsum | histsum2d[36]; hist, histsum and histsum2d
 // are the marginals of hist2d (ripcurrents_module.cpp:102-104 increments all four together).
@@ -710,8 +857,16 @@ extern "C" int rcflow_histogram_clip_dev(rc_ctx* ctx, int stream, const float* d
         int cap = (ctx->hist_blocks > 0 ? ctx->hist_blocks : 16384) / count;
         if (cap < 8) cap = 8;
         if (nb > cap) nb = cap;
-        hipLaunchKernelGGL(k_polar_hist<1>, dim3(nb, count), dim3(RC_BLOCK), 0, s->cur, d_flows, flow_frame_stride,
-                           flow_step, w, h, (int*)s->an.hist_part.p);
+        if (ctx->ablate & RC_ABL_HIST_V1) {
+            hipLaunchKernelGGL(k_polar_hist<1>, dim3(nb, count), dim3(RC_BLOCK), 0, s->cur, d_flows, flow_frame_stride,
+                               flow_step, w, h, (int*)s->an.hist_part.p);
+        } else {
+            // items are 2 x 4 pixel columns: a quarter of the items of the first form for the same block count
+            int nb4 = grid_for(((long long)(w + 1) / 2) * ((h + 3) / 4));
+            if (nb4 > cap) nb4 = cap;
+            hipLaunchKernelGGL(k_polar_hist_rows, dim3(nb4, count), dim3(RC_BLOCK), 0, s->cur, d_flows, flow_frame_stride,
+                               flow_step, w, h, (int*)s->an.hist_part.p);
+        }
         hipLaunchKernelGGL(k_hist_fold, dim3((RC_HIST_DIRECTIONS * RC_HIST_BINS + RC_BLOCK - 1) / RC_BLOCK),
                            dim3(RC_BLOCK), 0, s->cur, (int*)s->an.hist_part.p, (int*)s->an.hist.p);
     }

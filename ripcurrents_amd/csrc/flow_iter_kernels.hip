@@ -21,6 +21,12 @@
 #include "rc_device.h"
 
 #define RC_ITER_BATCH 3
+#ifndef RC_RR_D
+#define RC_RR_D 3         // displacements below this many pixels are served from the LDS window (28 x 28 tile)
+#endif
+#ifndef RC_RR_WPAD
+#define RC_RR_WPAD 0      // extra texels per LDS row of the register-row kernel's R1 window (see k_flow_iter2_rr)
+#endif
 
 // This file is compiled twice.  The default build (namespace rc_flow_fast) is the fast arithmetic:
 // sums of products as fused multiply-adds, the winsize-3 solve in fp32 (Kahan).  With -DRC_EXACT_BUILD
@@ -830,7 +836,7 @@ __device__ __forceinline__ void rc_glds4(const void* g, void* lds_wave_base) {
 
 // Bilinear gather of the 5 coefficients of R1 at p + flow: from the block's LDS window when
 // the 2x2 footprint lies inside it (|flow| < D), else from global memory.
-template <int WW, int WH>
+template <int WW, int WH, int WP = WW>
 __device__ __forceinline__ void rc_gather_window(RcGather& g, const float4* LA, const float* LB, int ox, int oy,
                                                  const float4* __restrict__ RA1, const float* __restrict__ RB1,
                                                  int gx, int gy, float dx, float dy, int w, int h) {
@@ -841,9 +847,9 @@ __device__ __forceinline__ void rc_gather_window(RcGather& g, const float4* LA, 
     g.inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
     const int wx = x1 - ox, wy = y1 - oy;
     if (g.inside && (unsigned)wx < (unsigned)(WW - 1) && (unsigned)wy < (unsigned)(WH - 1)) {
-        const int i = wy * WW + wx;
-        g.q00 = LA[i]; g.q01 = LA[i + 1]; g.q10 = LA[i + WW]; g.q11 = LA[i + WW + 1];
-        g.e00 = LB[i]; g.e01 = LB[i + 1]; g.e10 = LB[i + WW]; g.e11 = LB[i + WW + 1];
+        const int i = wy * WP + wx;
+        g.q00 = LA[i]; g.q01 = LA[i + 1]; g.q10 = LA[i + WP]; g.q11 = LA[i + WP + 1];
+        g.e00 = LB[i]; g.e01 = LB[i + 1]; g.e10 = LB[i + WP]; g.e11 = LB[i + WP + 1];
     } else {
         const size_t p = g.inside ? (size_t)y1 * w + x1 : (size_t)gy * w + gx;
         const size_t pw = g.inside ? (size_t)w : 0, p1 = g.inside ? 1 : 0;
@@ -1182,7 +1188,10 @@ __device__ __forceinline__ void rc_rr_exchange(const float (&m)[NIT][5], float* 
 template <int IN_MODE, int GAUSS_, int NIT, int D, int MINB, int MW, int NG>
 __global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
     constexpr int NT = NG * MW, MH = NG * NIT, TW = MW - 4, TH = MH - 4;    // NG groups of NIT rows, MW columns
-    constexpr int WW = MW + 2 * D, WH = MH + 2 * D, WN = WW * WH, NWL = (WN + NT - 1) / NT;
+    // The window's LDS row pitch WP: a wave's two half-waves sample rows NIT apart, so NIT * WP texels must be a
+    // multiple of 32 (512 B of float4s, 128 B of floats) for their 16-byte gathers to run at full rate; the
+    // WP - WW extra texels per row are loaded (they are real neighbours) but never sampled.
+    constexpr int WW = MW + 2 * D, WH = MH + 2 * D, WP = WW + RC_RR_WPAD, WN = WP * WH, NWL = (WN + NT - 1) / NT;
     constexpr int WNP = (WN + 63) & ~63;    // whole waves of LDS-DMA
     constexpr int MP = MW + 1, PLANE = MH * MP;
     static_assert(5 * PLANE <= 5 * WNP, "border-block M1 planes alias the R1 window");
@@ -1218,7 +1227,7 @@ __global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
 #pragma unroll
         for (int q = 0; q < NWL; q++) {
             int idx = tid + q * NT;
-            int wy = idx / WW, wx = idx - wy * WW;
+            int wy = idx / WP, wx = idx - wy * WP;
             int gx = ox + wx, gy = oy + wy;
             bool ok = idx < WN && (unsigned)gx < (unsigned)w && (unsigned)gy < (unsigned)h;
             size_t p = ok ? (size_t)gy * w + gx : 0;      // out-of-image texels are never read
@@ -1334,7 +1343,7 @@ __global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
 #pragma unroll
     for (int q = 0; q < NIT; q++) {
         RcGather g;
-        rc_gather_window<WW, WH>(g, LA, LB, ox, oy, RA1, RB1, gxo, gys[q], dx[q], dy[q], w, h);
+        rc_gather_window<WW, WH, WP>(g, LA, LB, ox, oy, RA1, RB1, gxo, gys[q], dx[q], dy[q], w, h);
         RcM5 v = rc_matrices_reg(A0[q], B0[q], g, dx[q], dy[q], gxo, gys[q], w, h, !interior);
         m[q][0] = v.m0; m[q][1] = v.m1; m[q][2] = v.m2; m[q][3] = v.m3; m[q][4] = v.m4;
     }
@@ -1348,7 +1357,7 @@ __global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
 #pragma unroll
         for (int q = 0; q < NIT; q++) {
             RcGather g;
-            rc_gather_window<WW, WH>(g, LA, LB, ox, oy, RA1, RB1, gxo, gys[q], f1[q].x, f1[q].y, w, h);
+            rc_gather_window<WW, WH, WP>(g, LA, LB, ox, oy, RA1, RB1, gxo, gys[q], f1[q].x, f1[q].y, w, h);
             RcM5 v = rc_matrices_reg(A0[q], B0[q], g, f1[q].x, f1[q].y, gxo, gys[q], w, h, !interior);
             m[q][0] = v.m0; m[q][1] = v.m1; m[q][2] = v.m2; m[q][3] = v.m3; m[q][4] = v.m4;
         }
@@ -1395,7 +1404,7 @@ static void launch_rr_t(RcIterArgs a, int pairs, hipStream_t s) {
     constexpr int MH = NG * NIT, TW = MW - 4, TH = MH - 4;
     a.tw = TW; a.th = TH;
     a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
-    constexpr int WN = (MW + 2 * D) * (MH + 2 * D), WNP = (WN + 63) & ~63;
+    constexpr int WN = (MW + 2 * D + RC_RR_WPAD) * (MH + 2 * D), WNP = (WN + 63) & ~63;
     size_t lds = sizeof(float) * (5 * WNP + NG * 2 * 5 * MW);
     RC_ALLOW_LDS((k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB, MW, NG>), lds);
     hipLaunchKernelGGL((k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB, MW, NG>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(NG * MW), lds, s, a);
@@ -1415,7 +1424,7 @@ static void launch_w3x2(RcIterArgs a, int pairs, hipStream_t s) {
         const long long blocks = (long long)((a.w + 27) / 28) * ((a.h + 27) / 28) * pairs;
         if (blocks < 512) launch_rr_t<IN_MODE, G, 2, 4, 6>(a, pairs, s);          // 28x12 tile
         else if (blocks < 1024) launch_rr_t<IN_MODE, G, 3, 4, 5>(a, pairs, s);    // 28x20 tile
-        else launch_rr_t<IN_MODE, G, 4, 3, 4>(a, pairs, s);                       // 28x28 tile, 4 blocks per CU
+        else launch_rr_t<IN_MODE, G, 4, RC_RR_D, 4>(a, pairs, s);                 // 28x28 tile, 4 blocks per CU
     }
 }
 

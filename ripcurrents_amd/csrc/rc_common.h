@@ -113,6 +113,7 @@ enum RcAblate : int {
     RC_ABL_TILE_WINDOW = 65536,      // Gaussian winsize 10 / 20: tile kernel even for large launches
     RC_ABL_SWEEP_512T = 131072,      // strip-sweep kernel with 512 threads
     RC_ABL_FORCE_SWEEP = 8388608,    // strip-sweep kernel even for small launches
+    RC_ABL_HIST_V1 = 16777216,       // histogram: the first form of the kernel (one scalar round per pixel, exact key everywhere)
 };
 
 struct RcIterArgs {
