@@ -90,6 +90,10 @@ def main():
     ap.add_argument("--sync-collective", action="store_true", help="N>1: all-reduce and thresholds inside the step (no one-step pipelining)")
     ap.add_argument("--clip-per-step", action="store_true", help="every step is an independent clip of pairs + 1 frames (pairs + 1 expansions)")
     ap.add_argument("--gaussian", action="store_true", help="main.cpp:264 variant (flags=256)")
+    ap.add_argument("--config", choices=["c1", "c2", "c3", "c5"], default="c2",
+                    help="BASELINE.json configuration: c2 (default, the headline) 1080p 3 scales; c1 640x480 translating texture; "
+                         "c3 3840x2160 5 scales (levels=4) + 250 seed streamlines and 5 streaklines per field; c5 16 lock-step 1080p "
+                         "streams per GPU through hipGraph replay.  Other than c2: own metric name, headline false")
     ap.add_argument("--mode", choices=["clip", "frame", "host", "host-stateless"], default="clip",
                     help="clip (default, the headline): 32 resident frames per call.  The reference-shaped loops, "
                          "reported under their own metric name, never as the headline: frame = one resident frame per "
@@ -125,11 +129,30 @@ def main():
     from ripcurrents_amd.api import Context
     from ripcurrents_amd.distributed import allreduce_hist_words, allreduce_hist_words_async, init_comm
 
+    global W, H
     params = dict(PARAMS)
     if args.gaussian:
         params["flags"] = 256
+    if args.config != "c2" and args.mode != "clip":
+        print("--mode applies to --config c2 only", file=sys.stderr)
+        sys.exit(2)
+    if args.config == "c1":
+        W, H = 640, 480
+    elif args.config == "c3":
+        W, H = 3840, 2160
+        params["levels"] = 4
+        if args.pairs == 32:
+            args.pairs = 8
+    elif args.config == "c5":
+        args.pairs = 16                      # 16 streams, one lock-step push per step
     T = args.pairs + 1
-    frames = synth.surf_clip(W, H, T, seed=1234 + rank, device=dev)      # generated in HBM
+    if args.config == "c1":
+        frames = synth.translating_clip(W, H, T, seed=1234 + rank, device=dev)
+    elif args.config == "c5":
+        # 16 independent streams: clips of 3 frames with different seeds, played forwards and backwards
+        frames = torch.stack([synth.surf_clip(W, H, 3, seed=1234 + 100 * rank + s_, device=dev) for s_ in range(16)])   # [S,3,H,W]
+    else:
+        frames = synth.surf_clip(W, H, T, seed=1234 + rank, device=dev)      # generated in HBM
     flows = torch.empty((args.pairs, H, W, 2), dtype=torch.float32, device=dev)
     ctx = Context(W, H, device=local_rank, streams=1)
     if args.chunk:
@@ -154,8 +177,23 @@ def main():
     # the last frame's expansion, so every frame is expanded exactly once (SURVEY 8(d)'s streaming model).  The
     # synthetic clip is played forwards, then backwards, then forwards ...: consecutive frames are always
     # neighbours in the clip.  --clip-per-step restores independent clips of pairs + 1 frames per step.
-    fwd = frames[1:]
-    bwd = frames.flip(0)[1:].contiguous()
+    if args.config == "c5":
+        c5_order = [0, 1, 2, 1]              # frame index per lock-step push: consecutive frames are always neighbours
+        c5_frames = [frames[:, i].contiguous() for i in range(3)]
+        c5_stage = torch.empty((16, H, W), dtype=torch.uint8, device=dev)    # the fixed staging buffer the graph captures
+        ctx.batch_reset()
+        c5_stage.copy_(c5_frames[0])
+        ctx.push_batch(c5_stage, flows, use_graph=True, **params)             # primes
+        fwd = bwd = frames
+    else:
+        fwd = frames[1:]
+        bwd = frames.flip(0)[1:].contiguous()
+    c3_seeds = c3_streak = None
+    if args.config == "c3":
+        from ripcurrents_amd.api import Streakline
+        g = torch.Generator(device="cpu").manual_seed(7)
+        c3_seeds = torch.stack([torch.rand(250, generator=g) * W, torch.rand(250, generator=g) * H], dim=1).float().to(dev)
+        c3_streak = torch.tensor([[W * (0.2 + 0.15 * i), H * 0.5] for i in range(5)], dtype=torch.float32, device=dev)
     host_fwd = host_bwd = host_flow = None
     host_last = [None]
     if args.mode in ("host", "host-stateless"):
@@ -166,6 +204,8 @@ def main():
     if args.mode == "host":
         ctx.stream_reset()
         ctx.push_frame_host(host_last[0], **params)
+    elif args.config == "c5":
+        pass
     elif args.mode == "frame" or not args.clip_per_step:
         ctx.stream_reset()
         ctx.push_clip(frames[0:1], flows, **params)          # primes the stream, no flow
@@ -175,7 +215,11 @@ def main():
         # a step is one segment of `pairs` frames: its histogram starts from zero (int32 counters:
         # 32 x 2.07 M counts per step; cumulative over the run they would wrap after ~32 steps)
         ctx.histogram_reset()
-        if args.mode == "frame":
+        if args.config == "c5":
+            nstep[0] += 1
+            c5_stage.copy_(c5_frames[c5_order[nstep[0] % 4]])                 # the 16 streams' next frames arrive (33 MB device copy)
+            ctx.push_batch(c5_stage, flows, use_graph=True, **params)
+        elif args.mode == "frame":
             seq = fwd if nstep[0] % 2 == 0 else bwd
             for t in range(args.pairs):
                 ctx.push_frame(seq[t], flows[t], **params)
@@ -201,6 +245,12 @@ def main():
             got = ctx.push_clip(fwd if nstep[0] % 2 == 0 else bwd, flows, **params)
             assert got.shape[0] == args.pairs
             nstep[0] += 1
+        if args.config == "c3":
+            # config 3's second half: the 250 seed streamlines (ripcurrents.cpp:170-172, :283-285) and the 5 streakline
+            # generation points (main.cpp:118) advected through every field of the step
+            for t in range(args.pairs):
+                ctx.streamline(c3_seeds, flows[t], 2.0, 1, 100.0, variant=3)
+                ctx.streamline(c3_streak, flows[t], 1.0, 1, 0.0, variant=4)
         ctx.histogram_accumulate_clip(flows)
         if world > 1:
             # global flow histogram: integer sum over RCCL, order independent; every
@@ -286,21 +336,27 @@ def main():
         model_b = survey_model_bytes_per_frame(W, H, params["levels"], params["iterations"])
         mode_names = {"clip": "", "frame": " [one resident frame per call]", "host": " [host frames, PCIe upload inclusive, flow resident]",
                       "host-stateless": " [two-image host-pointer drop-in, PCIe both ways, blocking]"}
+        cfg_names = {"c2": "@1080p", "c1": "@640x480 (config 1, translating texture)", "c3": "@3840x2160, 5 scales + streamline / streakline advection (config 3)",
+                     "c5": "@1080p, 16 lock-step streams per GPU, hipGraph replay (config 5)"}
         out = {
-            "metric": "frames/sec dense Farneback flow @1080p" + mode_names[args.mode],
-            "mode": args.mode, "headline": args.mode == "clip",
+            "metric": "frames/sec dense Farneback flow " + cfg_names[args.config] + mode_names[args.mode],
+            "bench_config": args.config, "mode": args.mode, "headline": args.mode == "clip" and args.config == "c2",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "C2 1920x1080 synthetic surf clip, 3 pyramid scales (levels=2), "
-                                   "winsize 3, iters 2, poly_n 15, sigma 1.2, flags %d; %d flow fields per "
-                                   "step per GPU, %s; + the flow histogram and thresholds of the step's fields (counters reset per step)"
-                                   % (params["flags"], args.pairs,
+            "config": {"workload": "%s %dx%d synthetic %s clip, %d pyramid scales (levels=%d), winsize 3, iters 2, poly_n 15, sigma 1.2, "
+                                   "flags %d; %d flow fields per step per GPU, %s; + the flow histogram and thresholds of the step's "
+                                   "fields (counters reset per step)%s"
+                                   % (args.config.upper(), W, H, "translating-texture" if args.config == "c1" else "surf",
+                                      params["levels"] + 1, params["levels"], params["flags"], args.pairs,
+                                      "16 independent streams advanced one frame in lock-step per step (rcflow_push_batch_dev, hipGraph replay)"
+                                      if args.config == "c5" else
                                       "an independent clip of %d frames per step (%d expansions)" % (args.pairs + 1, args.pairs + 1)
                                       if args.clip_per_step else
                                       "the next %d frames of a continuing segment per step (streaming model: every frame "
-                                      "expanded once; the clip is played forwards and backwards)" % args.pairs),
+                                      "expanded once; the clip is played forwards and backwards)" % args.pairs,
+                                      "; + 250 seed streamlines and 5 streakline points advected through every field" if args.config == "c3" else ""),
                        "pairs_per_step": args.pairs, "segments": world,
                        "collective": ("all_reduce int32[1887] per step" + ("" if args.sync_collective else ", overlapped with the next step")
                                       + (" (rcflow_allreduce_hist, librccl)" if use_cabi else " (torch.distributed)")) if world > 1 else "none"},
