@@ -436,6 +436,12 @@ void rc_launch_pyr(const RcPyrArgs& a, int frames, size_t lds, hipStream_t s) {
 // REFLECT_101; the resize is the identity) into the tile load, so the full-resolution
 // float image never exists in HBM.
 #define RC_POLY_BLOCK 512
+#ifndef RC_POLY_ABL
+#define RC_POLY_ABL 0     // timing-only ablations (never in the product): 1 = no R stores, 2 = the stores alone, 3 = staging + blur + pyramid alone
+#endif
+#ifndef RC_POLY_B128
+#define RC_POLY_B128 1    // horizontal pass: window reads as forced ds_read_b128 (0 = the compiler's choice)
+#endif
 
 typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -463,78 +469,89 @@ __device__ __forceinline__ float rc_lane_xor1(float v) {       // the value of l
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
 }
 
-// The tile's outputs of pyramid scales 1 (32 x 16) and 2 (16 x 8) at exact 2:1 / 4:1 sizes, from the
-// staged bytes: ub(row0, col0) = virtual image (row0, col0), REFLECT_101 applied by the staging.
-// A thread takes two vertically adjacent outputs, which share row-filter results (6 instead of 8 rows
-// at scale 1, 14 instead of 20 at scale 2); at scale 2 two lanes share the pair, one sampled column
-// each.  Operation order per output is rc_pyr_direct_body's (row filter at the two sampled columns,
-// column filter at the two sampled rows, bilinear weights 1 - 0.5 and 0.5): same bits.
-template <int R>
-__device__ __forceinline__ void rc_polyexp_pyr_phase(const RcPolyArgs& a, const unsigned char* ub, int pitch, int row0,
-                                                     int col0, int tx0, int ty0, int slot, int tid) {
+// The tile's outputs of pyramid scales 1 (32 x 16) and 2 (16 x 8) at exact 2:1 / 4:1 sizes.
+//
+// Scale 2 (9 float taps, sigma 1.5) from the staged bytes, in two steps that every thread of the block shares:
+//   rc_pyr2_rows  the row filter at the 32 sampled columns (two per output) of the 38 source rows the tile's 8 output
+//                 rows touch -> LDS [38][32]   (1216 row filters per tile; a thread per output pair used to evaluate
+//                 14 of them on its own -- 1792 per tile on 128 threads while the other 384 waited at the barrier:
+//                 that phase was 32 % of the block's lifetime by s_memtime stamps)
+//   rc_pyr2_cols  128 threads: column filter at the two sampled rows, bilinear weights (0.5, 0.5), store.
+// Operation order per output is rc_pyr_direct_body's / the oracle's (row filter, column filter, resize): same bits.
+//
+__device__ __forceinline__ void rc_pyr2_rows(const RcPolyArgs& a, const unsigned char* ub, int pitch, int row0, int col0,
+                                             int tx0, int ty0, int tid, float* rp2) {
+    const RcPyrFused& P = a.py[1];
+    float k[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) k[j] = P.kern[j];
+    for (int item = tid; item < 38 * 32; item += RC_POLY_BLOCK) {
+        const int r = item >> 5, c = item & 31;
+        // source row ty0 - 3 + r; sampled column 4 (ox) + 1 + (c & 1) of output ox = c >> 1, taps -4 .. +4
+        const unsigned char* u0 = ub + (ty0 - 3 + r - row0) * pitch + (tx0 + 4 * (c >> 1) + 1 + (c & 1) - 4 - col0);
+        float b[9];
+        rc_lds_bytes_f32<9>(u0, b);
+        rp2[item] = rc_rowpass<4>(b, k);
+    }
+}
+
+__device__ __forceinline__ void rc_pyr2_cols(const RcPolyArgs& a, const float* rp2, int tx0, int ty0, int slot, int t) {
+    const RcPyrFused& P = a.py[1];
     const float a0 = 1.f - 0.5f, a1 = 0.5f;
-    const int t1 = a.npyr >= 2 ? tid - 128 : tid;            // scale 1: 256 threads, one output pair each
-    if (a.npyr >= 2 && tid < 128) {
-        const RcPyrFused& P = a.py[1];
-        const int c = tid & 1, o = tid >> 1, ox = o & 15, oyp = o >> 4;
-        const int dx = (tx0 >> 2) + ox, dy = (ty0 >> 2) + 2 * oyp;
-        // source samples (4 dx + 1.5, 4 dy + 1.5): columns 4dx+1 (c = 0) / 4dx+2 (c = 1), rows 4dy+1, 4dy+2; 9 taps
-        const unsigned char* u0 = ub + (ty0 + 8 * oyp + 1 - 4 - row0) * pitch + (tx0 + 4 * ox + 1 - 4 + c - col0);
-        float k[9];
+    const int ox = t & 15, oy = t >> 4;
+    const int dx = (tx0 >> 2) + ox, dy = (ty0 >> 2) + oy;
+    if (dx >= P.w || dy >= P.h) return;
+    float k[9];
 #pragma unroll
-        for (int j = 0; j < 9; j++) k[j] = P.kern[j];
-        float rp[14];
+    for (int j = 0; j < 9; j++) k[j] = P.kern[j];
+    // sampled rows 4 dy + 1 and + 2 -> rp2 rows 4 oy + 4 and + 5; sampled columns 2 ox and 2 ox + 1
+    const float* c0 = rp2 + (4 * oy + 4) * 32 + 2 * ox;
+    float b0 = k[4] * c0[0], o0 = k[4] * c0[1], b1 = k[4] * c0[32], o1 = k[4] * c0[33];
 #pragma unroll
-        for (int rr = 0; rr < 14; rr++) {
-            float b[9];
-            rc_lds_bytes_f32<9>(u0 + rr * pitch, b);
-            rp[rr] = rc_rowpass<4>(b, k);
-        }
+    for (int j = 1; j <= 4; j++) {
+        b0 += k[4 + j] * (c0[j * 32] + c0[-j * 32]);
+        o0 += k[4 + j] * (c0[j * 32 + 1] + c0[-j * 32 + 1]);
+        b1 += k[4 + j] * (c0[(j + 1) * 32] + c0[(1 - j) * 32]);
+        o1 += k[4 + j] * (c0[(j + 1) * 32 + 1] + c0[(1 - j) * 32 + 1]);
+    }
+    const float r0 = b0 * a0 + o0 * a1;
+    const float r1 = b1 * a0 + o1 * a1;
+    P.dst[(size_t)slot * P.dst_slot_stride + (size_t)dy * P.w + dx] = r0 * a0 + r1 * a1;
+}
+
+// Scale 1 (3 float taps of sigma 0.5 -- NOT the fixed 1/4 1/2 1/4 of scale 0, so the tile's blurred image cannot be
+// reused): one thread per pair of vertically adjacent outputs (they share 4 of their 6 row-filter rows), 256 threads.
+__device__ __forceinline__ void rc_pyr1_pairs(const RcPolyArgs& a, const unsigned char* ub, int pitch, int row0, int col0,
+                                              int tx0, int ty0, int slot, int t1) {
+    const float a0 = 1.f - 0.5f, a1 = 0.5f;
+    const RcPyrFused& P = a.py[0];
+    const int ox = t1 & 31, oyp = t1 >> 5;
+    const int dx = (tx0 >> 1) + ox, dy = (ty0 >> 1) + 2 * oyp;
+    // source samples (2 dx + 0.5, 2 dy + 0.5): columns 2dx, 2dx+1, rows 2dy, 2dy+1; 3 taps
+    const unsigned char* u0 = ub + (ty0 + 4 * oyp - 1 - row0) * pitch + (tx0 + 2 * ox - 1 - col0);
+    float k[3];
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-            float b0 = k[4] * rp[4 * e + 4], b1 = k[4] * rp[4 * e + 5];
+    for (int j = 0; j < 3; j++) k[j] = P.kern[j];
+    float rp0[6], rp1[6];
 #pragma unroll
-            for (int j = 1; j <= 4; j++) {
-                b0 += k[4 + j] * (rp[4 * e + 4 + j] + rp[4 * e + 4 - j]);
-                b1 += k[4 + j] * (rp[4 * e + 5 + j] + rp[4 * e + 5 - j]);
-            }
-            const float o0 = rc_lane_xor1(b0), o1 = rc_lane_xor1(b1);      // the other sampled column
-            if (c == 0 && dx < P.w && dy + e < P.h) {
-                float r0 = b0 * a0 + o0 * a1;
-                float r1 = b1 * a0 + o1 * a1;
-                P.dst[(size_t)slot * P.dst_slot_stride + (size_t)(dy + e) * P.w + dx] = r0 * a0 + r1 * a1;
-            }
-        }
-    } else if (a.npyr >= 1 && t1 < 256) {
-        const RcPyrFused& P = a.py[0];
-        const int ox = t1 & 31, oyp = t1 >> 5;
-        const int dx = (tx0 >> 1) + ox, dy = (ty0 >> 1) + 2 * oyp;
-        // source samples (2 dx + 0.5, 2 dy + 0.5): columns 2dx, 2dx+1, rows 2dy, 2dy+1; 3 taps
-        const unsigned char* u0 = ub + (ty0 + 4 * oyp - 1 - row0) * pitch + (tx0 + 2 * ox - 1 - col0);
-        float k[3];
+    for (int rr = 0; rr < 6; rr++) {
+        float b[4];
+        rc_lds_bytes_f32<4>(u0 + rr * pitch, b);
+        rp0[rr] = rc_rowpass<1>(b, k);
+        rp1[rr] = rc_rowpass<1>(b + 1, k);
+    }
 #pragma unroll
-        for (int j = 0; j < 3; j++) k[j] = P.kern[j];
-        float rp0[6], rp1[6];
-#pragma unroll
-        for (int rr = 0; rr < 6; rr++) {
-            float b[4];
-            rc_lds_bytes_f32<4>(u0 + rr * pitch, b);
-            rp0[rr] = rc_rowpass<1>(b, k);
-            rp1[rr] = rc_rowpass<1>(b + 1, k);
-        }
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-            float b00 = k[1] * rp0[2 * e + 1], b01 = k[1] * rp1[2 * e + 1];
-            float b10 = k[1] * rp0[2 * e + 2], b11 = k[1] * rp1[2 * e + 2];
-            b00 += k[2] * (rp0[2 * e + 2] + rp0[2 * e]);
-            b01 += k[2] * (rp1[2 * e + 2] + rp1[2 * e]);
-            b10 += k[2] * (rp0[2 * e + 3] + rp0[2 * e + 1]);
-            b11 += k[2] * (rp1[2 * e + 3] + rp1[2 * e + 1]);
-            if (dx < P.w && dy + e < P.h) {
-                float r0 = b00 * a0 + b01 * a1;
-                float r1 = b10 * a0 + b11 * a1;
-                P.dst[(size_t)slot * P.dst_slot_stride + (size_t)(dy + e) * P.w + dx] = r0 * a0 + r1 * a1;
-            }
+    for (int e = 0; e < 2; e++) {
+        float b00 = k[1] * rp0[2 * e + 1], b01 = k[1] * rp1[2 * e + 1];
+        float b10 = k[1] * rp0[2 * e + 2], b11 = k[1] * rp1[2 * e + 2];
+        b00 += k[2] * (rp0[2 * e + 2] + rp0[2 * e]);
+        b01 += k[2] * (rp1[2 * e + 2] + rp1[2 * e]);
+        b10 += k[2] * (rp0[2 * e + 3] + rp0[2 * e + 1]);
+        b11 += k[2] * (rp1[2 * e + 3] + rp1[2 * e + 1]);
+        if (dx < P.w && dy + e < P.h) {
+            float r0 = b00 * a0 + b01 * a1;
+            float r1 = b10 * a0 + b11 * a1;
+            P.dst[(size_t)slot * P.dst_slot_stride + (size_t)(dy + e) * P.w + dx] = r0 * a0 + r1 * a1;
         }
     }
 }
@@ -546,6 +563,14 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
     constexpr int INW = TW + 2 * RP, INH = TH + 2 * R;
     constexpr int NV = 4 + 2 * RP;
     constexpr int NDW = (INW + 8) / 4, UBW = 4 * NDW, UBH = INH + 2;   // u8 staging: pitch UBW bytes
+#ifdef RC_STAMPS   // diagnostic build only: s_memtime phase stamps of every 61st tile of frame 0 (scripts/r2/poly_stamps.py)
+    const bool stamp_on = a.stamps && threadIdx.x == 0 && z == 0 && ((bx + by * 30) % 61) == 0;
+    long long* stp = a.stamps ? a.stamps + (size_t)((bx + by * 30) / 61) * 8 : nullptr;
+#define RC_PSTAMP(i) if (stamp_on) stp[i] = __builtin_amdgcn_s_memtime()
+#else
+#define RC_PSTAMP(i)
+#endif
+    RC_PSTAMP(0);
     float* tin = smf;                // [INH][INW]
     float* hs = smf + INH * INW;     // [3][INH][TW]
     const int tid = threadIdx.x;
@@ -557,6 +582,8 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
     if constexpr (U8) {
         // the u8 staging area lives in hs: it is dead before the horizontal pass writes there
         unsigned char* ub = (unsigned char*)hs;                    // [UBH][UBW]
+        float* rp2 = (float*)(ub + ((UBH * UBW + 15) & ~15));      // [38][32] scale-2 row-filter results (PYR)
+        static_assert(!PYR || ((UBH * UBW + 15) & ~15) + 38 * 32 * 4 <= 3 * INH * TW * 4, "scale-2 rows fit the dead planes");
         const uint8_t* src = a.src8 + (size_t)z * a.src8_frame_stride;
         dc = (float)src[(size_t)min(ty0 + TH / 2, h - 1) * a.src8_step + min(tx0 + TW / 2, w - 1)];
         const int ylo = PYR ? ty0 - R - 1 : rc_clampi(ty0 - R, 0, h - 1) - 1;   // image (PYR: virtual) row of staging row 0
@@ -584,9 +611,32 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
                 if (idx < UBH * NDW) ((unsigned int*)ub)[idx] = v[q];
             }
             __syncthreads();
-            if constexpr (PYR) rc_polyexp_pyr_phase<R>(a, ub, UBW, ylo, xs, tx0, ty0, slot, tid);
+            RC_PSTAMP(1);
+            if constexpr (PYR) {
+                // scale 2's row filters on every wave, then the block splits: two waves finish scale 2, four do scale
+                // 1, and whoever is free takes the next 64 blur items from a shared counter
+                if (a.npyr >= 2) {       // block-uniform
+                    rc_pyr2_rows(a, ub, UBW, ylo, xs, tx0, ty0, tid, rp2);
+                    __syncthreads();
+                    if (tid >= RC_POLY_BLOCK - 128) rc_pyr2_cols(a, rp2, tx0, ty0, slot, tid - (RC_POLY_BLOCK - 128));
+                    else if (tid >= RC_POLY_BLOCK - 384) rc_pyr1_pairs(a, ub, UBW, ylo, xs, tx0, ty0, slot, tid - (RC_POLY_BLOCK - 384));
+                } else if (tid < 256) {
+                    rc_pyr1_pairs(a, ub, UBW, ylo, xs, tx0, ty0, slot, tid);
+                }
+            }
+            RC_PSTAMP(2);
             const float mdc = -dc;
-            for (int idx = tid; idx < INH * (INW / 4); idx += RC_POLY_BLOCK) {
+            // Blur items (4 pixels each).  With the fused pyramid the waves have unequal work behind them (waves 6-7:
+            // scale-2 columns, waves 2-5: scale 1, waves 0-1: nothing), so the items are dealt in eight slots of 128:
+            // slots 0-3 to waves 0-1 (four items per thread), 4-5 to waves 2-5, 6-7 to waves 6-7.
+            constexpr int NBLUR = INH * (INW / 4);
+            static_assert(!PYR || NBLUR <= 1024, "eight slots of 128 blur items");
+            const bool dealt = PYR && a.npyr >= 2;
+            const int nit = !dealt ? (NBLUR + RC_POLY_BLOCK - 1) / RC_POLY_BLOCK : (tid < 128 ? 4 : (tid < 384 ? 1 : 2));
+            const int it0 = !dealt ? tid : (tid < 128 ? tid : 384 + tid), its = !dealt ? RC_POLY_BLOCK : 128;
+            for (int q = 0; q < nit; q++) {
+                const int idx = it0 + q * its;
+                if (idx < NBLUR) {
                 int i = idx / (INW / 4), j4 = idx - i * (INW / 4);
                 // tin(i, 4 j4 + p) is centred on staging byte 4 j4 + 4 + p of the row of image line gy
                 int gy = rc_clampi(ty0 - R + i, 0, h - 1);
@@ -610,6 +660,7 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
                 o.z = RC_FMA((float)(o02 >> 16), 0.0625f, mdc);
                 o.w = RC_FMA((float)(o13 >> 16), 0.0625f, mdc);
                 *(float4*)(tin + i * INW + 4 * j4) = o;
+                }
             }
         } else {
             const int xlo = PYR ? tx0 - RP - 1 : rc_clampi(tx0 - RP, 0, w - 1) - 1;
@@ -630,7 +681,16 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
                 if (idx < UBH * UBWS) ub[i * UBW + j] = v[q];
             }
             __syncthreads();
-            if constexpr (PYR) rc_polyexp_pyr_phase<R>(a, ub, UBW, ylo, xlo, tx0, ty0, slot, tid);
+            if constexpr (PYR) {
+                if (a.npyr >= 2) {
+                    rc_pyr2_rows(a, ub, UBW, ylo, xlo, tx0, ty0, tid, rp2);
+                    __syncthreads();
+                    if (tid < 128) rc_pyr2_cols(a, rp2, tx0, ty0, slot, tid);
+                    else if (tid < 384) rc_pyr1_pairs(a, ub, UBW, ylo, xlo, tx0, ty0, slot, tid - 128);
+                } else if (tid < 256) {
+                    rc_pyr1_pairs(a, ub, UBW, ylo, xlo, tx0, ty0, slot, tid);
+                }
+            }
             for (int idx = tid; idx < INH * INW; idx += RC_POLY_BLOCK) {
                 int i = idx / INW, j = idx - i * INW;
                 int gy = rc_clampi(ty0 - R + i, 0, h - 1), gx = rc_clampi(tx0 - RP + j, 0, w - 1);
@@ -662,17 +722,65 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
         }
     }
     __syncthreads();
+    RC_PSTAMP(3);
+#if RC_POLY_ABL == 3
+    if (a.w > 0) {   // timing-only build: staging + blur (+ fused pyramid) alone
+        if (tin[tid] == 12345.678f) a.RB[0] = 1.f;
+        return;
+    }
+#endif
+#if RC_POLY_ABL == 2
+    if (a.w > 0) {   // timing-only build: the stores alone
+        constexpr int NR_ = TH / (RC_POLY_BLOCK / 64);
+        const int x_ = tid & 63, o0_ = (tid >> 6) * NR_, gx_ = tx0 + x_;
+        if (gx_ < w) {
+            float4* RA_ = a.RA + (size_t)slot * a.R_slot_stride;
+            float* RB_ = a.RB + (size_t)slot * a.R_slot_stride;
+            for (int o = 0; o < NR_; o++) {
+                int gy = ty0 + o0_ + o;
+                if (gy < h) {
+                    size_t p = (size_t)gy * w + gx_;
+                    const float c = tin[(o0_ + o) * INW + x_];
+                    __builtin_nontemporal_store(c, &RA_[p].x); __builtin_nontemporal_store(c, &RA_[p].y);
+                    __builtin_nontemporal_store(c, &RA_[p].z); __builtin_nontemporal_store(c, &RA_[p].w);
+                    __builtin_nontemporal_store(c, &RB_[p]);
+                }
+            }
+        }
+        return;
+    }
+#endif
 
     // horizontal pass: item = (row i, group of 4 pixels)
     for (int idx = tid; idx < INH * (TW / 4); idx += RC_POLY_BLOCK) {
         int i = idx / (TW / 4), g4 = idx - i * (TW / 4);
         float v[NV];
+#if RC_POLY_B128
+        // 16-byte LDS reads, forced: left to itself the compiler drops the two taps of the window it never uses
+        // and fetches the other 18 floats as nine ds_read2_b32 at odd dword offsets -- a stride-4-dword pattern
+        // that lands the wave's 64 lanes on 16 banks (4-way conflicts).  Measured: -1.2 % of the kernel.
+        {
+            const unsigned la = (unsigned)(size_t)((__attribute__((address_space(3))) float*)(tin + i * INW + 4 * g4));
+            rc_f32x4 t[NV / 4];
+#pragma unroll
+            for (int q = 0; q < NV / 4; q++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t[q]) : "v"(la), "n"(16 * q));
+            if constexpr (NV / 4 == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]));
+            else if constexpr (NV / 4 == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]));
+            else {
+#pragma unroll
+                for (int q = 0; q < NV / 4; q++) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[q]));
+            }
+#pragma unroll
+            for (int q = 0; q < NV / 4; q++) { v[4 * q] = t[q].x; v[4 * q + 1] = t[q].y; v[4 * q + 2] = t[q].z; v[4 * q + 3] = t[q].w; }
+        }
+#else
         const float4* p4 = (const float4*)(tin + i * INW + 4 * g4);
 #pragma unroll
         for (int q = 0; q < NV / 4; q++) {
             float4 t = p4[q];
             v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
         }
+#endif
         float h0[4], h1[4], h2[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) {
@@ -751,6 +859,7 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
         }
         return;
     }
+    RC_PSTAMP(4);
     // vertical pass: lane = column, NR output rows per thread
     constexpr int NR = TH / (RC_POLY_BLOCK / 64);
     static_assert(NR * (RC_POLY_BLOCK / 64) == TH, "tile height must be a multiple of 8");
@@ -807,10 +916,15 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
         float* RB = a.RB + (size_t)slot * a.R_slot_stride;
         const double dck = (double)dc * a.pk.kdc;
         const float ig11f = (float)a.pk.ig11, ig55f = (float)a.pk.ig55;
+        RC_PSTAMP(5);
 #pragma unroll
         for (int o = 0; o < NR; o++) {
             int gy = ty0 + o0 + o;
+#if RC_POLY_ABL == 1
+            if (gy < h && b1[o] == 12345.678f) {      // timing-only build: everything but the stores
+#else
             if (gy < h) {
+#endif
                 float4 ra;
                 ra.x = b3[o] * ig11f;
                 ra.y = b2[o] * ig11f;
@@ -825,6 +939,10 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
             }
         }
     }
+    RC_PSTAMP(6);
+#ifdef RC_STAMPS
+    if (stamp_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stp[7] = __builtin_amdgcn_s_memtime(); }   // stores acknowledged
+#endif
 }
 
 template <int R, int U8, int TH, int MFMA, int PYR = 0>

@@ -89,6 +89,7 @@ struct RcPolyArgs {
     int tile_h;               // rows per block: 32 or 48 (option "poly_tile_h")
     int no_fast_u8;           // diagnostic: byte-wise staging for every tile
     int valu_vertical;        // option "poly_mfma" = 0: vertical pass on the VALU instead of the matrix cores
+    long long* stamps;        // diagnostic s_memtime stamps (RC_STAMPS builds; null in production)
     RcPolyK pk;
     int npyr;                 // scale 0 only: pyramid scales 1..npyr come out of this launch too
     RcPyrFused py[2];

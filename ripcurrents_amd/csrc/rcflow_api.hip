@@ -594,6 +594,7 @@ static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t fr
         q.RA = (float4*)s.RA[k].p; q.RB = (float*)s.RB[k].p; q.R_slot_stride = n;
         q.slot0 = dslot0; q.nslots = pl.nslots; q.zstep = zstep; q.w = L.w; q.h = L.h; q.pk = pl.pk;
         q.tile_h = ctx->poly_tile_h; q.no_fast_u8 = (ctx->ablate & RC_ABL_NO_FAST_U8) != 0; q.valu_vertical = !ctx->poly_mfma;
+        q.stamps = (k == 0) ? (long long*)ctx->stamps : nullptr;
         if (k == 0 && !pl.exact) {
             // scale 0: pyramid (3x3 blur, identity resize) fused into the expansion
             q.src8 = d_src; q.src8_step = step; q.src8_frame_stride = frame_stride;
