@@ -507,6 +507,129 @@ void update_flow_gaussian(const float* R0, const float* R1, float* flow_, float*
     }
 }
 
+// Multi-threaded forms for the CPU baseline on all cores and for the full-size GPU tests (a 4K pair in a second
+// instead of three).  They rely on the equivalence the CPU tier proves (test_stripe_update_equals_whole_image):
+// upstream's in-loop stripe update of M equals "window + solve the whole image, then update every matrix".
+// Box window: every column's running sum is its own sequential chain (threads split the columns), every row's
+// running sum likewise (threads split the rows), so each chain sees exactly the operations of the sequential
+// code above: same bits (oracle_kat compares 1 and 3 threads).
+void update_flow_blur_mt(const float* R0, const float* R1, float* flow_, float* matM, int width, int height,
+                         int block_size, bool update, int nthreads, float* gout, std::vector<double>& V) {
+    const int m = block_size / 2;
+    const double scale = 1. / (block_size * block_size);
+    const size_t row5 = (size_t)width * 5;
+    if (V.size() < (size_t)height * row5) V.resize((size_t)height * row5);     // the caller keeps it across scales and iterations
+    parallel_rows(width, nthreads, [&](int xa, int xb) {      // column ranges
+        const size_t a5 = (size_t)xa * 5, b5 = (size_t)xb * 5;
+        std::vector<double> vs(b5 - a5);
+        for (size_t x = a5; x < b5; x++) vs[x - a5] = matM[x] * (m + 2);
+        for (int y = 1; y < m; y++) {
+            const float* r = matM + (size_t)std::min(y, height - 1) * row5;
+            for (size_t x = a5; x < b5; x++) vs[x - a5] += r[x];
+        }
+        for (int y = 0; y < height; y++) {
+            const float* s0 = matM + (size_t)std::max(y - m - 1, 0) * row5;
+            const float* s1 = matM + (size_t)std::min(y + m, height - 1) * row5;
+            double* o = V.data() + (size_t)y * row5;
+            for (size_t x = a5; x < b5; x++) {
+                vs[x - a5] += s1[x] - s0[x];
+                o[x] = vs[x - a5];
+            }
+        }
+    });
+    parallel_rows(height, nthreads, [&](int ya, int yb) {
+        std::vector<double> _vsum((size_t)(width + m * 2 + 2) * 5);
+        double* vsum = _vsum.data() + (m + 1) * 5;
+        for (int y = ya; y < yb; y++) {
+            std::memcpy(vsum, V.data() + (size_t)y * row5, sizeof(double) * row5);
+            for (int x = 0; x < (m + 1) * 5; x++) {
+                vsum[-1 - x] = vsum[4 - x];
+                vsum[width * 5 + x] = vsum[width * 5 + x - 5];
+            }
+            double g11 = vsum[0] * (m + 2), g12 = vsum[1] * (m + 2), g22 = vsum[2] * (m + 2);
+            double h1 = vsum[3] * (m + 2), h2 = vsum[4] * (m + 2);
+            for (int x = 1; x < m; x++) {
+                g11 += vsum[x * 5]; g12 += vsum[x * 5 + 1]; g22 += vsum[x * 5 + 2];
+                h1 += vsum[x * 5 + 3]; h2 += vsum[x * 5 + 4];
+            }
+            float* flow = flow_ + (size_t)y * width * 2;
+            for (int x = 0; x < width; x++) {
+                g11 += vsum[(x + m) * 5] - vsum[(x - m) * 5 - 5];
+                g12 += vsum[(x + m) * 5 + 1] - vsum[(x - m) * 5 - 4];
+                g22 += vsum[(x + m) * 5 + 2] - vsum[(x - m) * 5 - 3];
+                h1 += vsum[(x + m) * 5 + 3] - vsum[(x - m) * 5 - 2];
+                h2 += vsum[(x + m) * 5 + 4] - vsum[(x - m) * 5 - 1];
+                double g11_ = g11 * scale, g12_ = g12 * scale, g22_ = g22 * scale;
+                double h1_ = h1 * scale, h2_ = h2 * scale;
+                double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
+                flow[x * 2] = (float)((g11_ * h2_ - g12_ * h1_) * idet);
+                flow[x * 2 + 1] = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+                if (gout) {
+                    float* go = gout + ((size_t)y * width + x) * 3;
+                    go[0] = (float)g11_; go[1] = (float)g12_; go[2] = (float)g22_;
+                }
+            }
+        }
+    });
+    if (update)
+        parallel_rows(height, nthreads, [&](int ya, int yb) { update_matrices(R0, R1, flow_, matM, width, height, ya, yb); });
+}
+
+// Gaussian window: rows are independent once M is read-only for the whole pass.
+void update_flow_gaussian_mt(const float* R0, const float* R1, float* flow_, float* matM, int width, int height,
+                             int block_size, bool update, int nthreads, float* gout) {
+    const int m = block_size / 2;
+    const double sigma = m * 0.3;
+    double s = 1;
+    std::vector<float> kernel(m + 1);
+    kernel[0] = (float)s;
+    for (int i = 1; i <= m; i++) {
+        float t = (float)std::exp(-i * i / (2 * sigma * sigma));
+        kernel[i] = t;
+        s += t * 2;
+    }
+    s = 1. / s;
+    for (int i = 0; i <= m; i++) kernel[i] = (float)(kernel[i] * s);
+    parallel_rows(height, nthreads, [&](int ya, int yb) {
+        std::vector<float> _vsum((size_t)(width + m * 2 + 2) * 5), hsum((size_t)width * 5);
+        std::vector<const float*> srow(m * 2 + 1);
+        float* vsum = _vsum.data() + (m + 1) * 5;
+        for (int y = ya; y < yb; y++) {
+            for (int i = 0; i <= m; i++) {
+                srow[m - i] = matM + (size_t)std::max(y - i, 0) * width * 5;
+                srow[m + i] = matM + (size_t)std::min(y + i, height - 1) * width * 5;
+            }
+            for (int x = 0; x < width * 5; x++) {
+                float s0 = srow[m][x] * kernel[0];
+                for (int i = 1; i <= m; i++) s0 += (srow[m + i][x] + srow[m - i][x]) * kernel[i];
+                vsum[x] = s0;
+            }
+            for (int x = 0; x < m * 5; x++) {
+                vsum[-1 - x] = vsum[4 - x];
+                vsum[width * 5 + x] = vsum[width * 5 + x - 5];
+            }
+            for (int x = 0; x < width * 5; x++) {
+                float sum = vsum[x] * kernel[0];
+                for (int i = 1; i <= m; i++) sum += kernel[i] * (vsum[x - i * 5] + vsum[x + i * 5]);
+                hsum[x] = sum;
+            }
+            float* flow = flow_ + (size_t)y * width * 2;
+            for (int x = 0; x < width; x++) {
+                double g11 = hsum[x * 5], g12 = hsum[x * 5 + 1], g22 = hsum[x * 5 + 2], h1 = hsum[x * 5 + 3], h2 = hsum[x * 5 + 4];
+                double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                flow[x * 2] = (float)((g11 * h2 - g12 * h1) * idet);
+                flow[x * 2 + 1] = (float)((g22 * h1 - g12 * h2) * idet);
+                if (gout) {
+                    float* go = gout + ((size_t)y * width + x) * 3;
+                    go[0] = (float)g11; go[1] = (float)g12; go[2] = (float)g22;
+                }
+            }
+        }
+    });
+    if (update)
+        parallel_rows(height, nthreads, [&](int ya, int yb) { update_matrices(R0, R1, flow_, matM, width, height, ya, yb); });
+}
+
 struct LevelGeom {
     int w, h, ksize;
     double sigma, scale;
@@ -624,6 +747,8 @@ int orc_farneback_u8_ex(const uint8_t* prev, size_t prev_step, const uint8_t* ne
     levels = crop_levels(w, h, pyr_scale, levels);
 
     std::vector<float> prevFlow, flow;
+    std::vector<double> Vscratch;
+    if (nthreads > 1 && !(flags & ORC_FARNEBACK_GAUSSIAN)) Vscratch.resize((size_t)w * h * 5);    // scale 0 is the largest
     int pw = 0, ph = 0;
     for (int k = levels; k >= 0; k--) {
         LevelGeom g = level_geom(w, h, pyr_scale, k);
@@ -640,17 +765,22 @@ int orc_farneback_u8_ex(const uint8_t* prev, size_t prev_step, const uint8_t* ne
             R[i].resize((size_t)width * height * 5);
             polyexp(I.data(), width, height, poly_n, poly_sigma, R[i].data(), nthreads);
         }
-        update_matrices(R[0].data(), R[1].data(), flow.data(), M.data(), width, height, 0, height);
+        parallel_rows(height, nthreads, [&](int ya, int yb) {
+            update_matrices(R[0].data(), R[1].data(), flow.data(), M.data(), width, height, ya, yb);
+        });
         const bool want_g = dg && (dg->det_min || (k == 0 && dg->g_last));
         std::vector<float> gbuf(want_g ? (size_t)width * height * 3 : 0);
         std::vector<float> dmin(dg && dg->det_min ? (size_t)width * height : 0, FLT_MAX);
         for (int i = 0; i < iters; i++) {
-            if (flags & ORC_FARNEBACK_GAUSSIAN)
-                update_flow_gaussian(R[0].data(), R[1].data(), flow.data(), M.data(), width,
-                                     height, winsize, i < iters - 1, want_g ? gbuf.data() : nullptr);
-            else
-                update_flow_blur(R[0].data(), R[1].data(), flow.data(), M.data(), width, height,
-                                 winsize, i < iters - 1, want_g ? gbuf.data() : nullptr);
+            float* gp = want_g ? gbuf.data() : nullptr;
+            const bool mt = nthreads > 1 && height >= 2 * nthreads && width >= 2 * nthreads;
+            if (flags & ORC_FARNEBACK_GAUSSIAN) {
+                if (mt) update_flow_gaussian_mt(R[0].data(), R[1].data(), flow.data(), M.data(), width, height, winsize, i < iters - 1, nthreads, gp);
+                else update_flow_gaussian(R[0].data(), R[1].data(), flow.data(), M.data(), width, height, winsize, i < iters - 1, gp);
+            } else {
+                if (mt) update_flow_blur_mt(R[0].data(), R[1].data(), flow.data(), M.data(), width, height, winsize, i < iters - 1, nthreads, gp, Vscratch);
+                else update_flow_blur(R[0].data(), R[1].data(), flow.data(), M.data(), width, height, winsize, i < iters - 1, gp);
+            }
             for (size_t p = 0; p < dmin.size(); p++) {
                 const float* go = gbuf.data() + p * 3;
                 dmin[p] = std::min(dmin[p], (float)((double)go[0] * go[2] - (double)go[1] * go[1]));
