@@ -21,6 +21,9 @@
 #include "rc_device.h"
 
 #define RC_ITER_BATCH 3
+#ifndef RC_RR_ABL
+#define RC_RR_ABL 0       // timing-only ablations of k_flow_iter2_rr (never in the product): 1 = the loads alone, 2 = no global loads
+#endif
 #ifndef RC_RR_D
 #define RC_RR_D 3         // displacements below this many pixels are served from the LDS window (28 x 28 tile)
 #endif
@@ -1222,6 +1225,9 @@ __global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
     const bool interior = tx0 - 2 >= 5 && tx0 - 2 + MW <= w - 5 && ty0 - 2 >= 5 && ty0 - 2 + MH <= h - 5;
 
     // ---- every global load of the block, issued together
+#if RC_RR_ABL == 2
+    if (a.w < 0)        // timing-only build: no global loads (the compute runs on whatever LDS holds)
+#endif
     {
         const int wave_base = tid & ~63;
 #pragma unroll
@@ -1242,8 +1248,14 @@ __global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
 #pragma unroll
     for (int q = 0; q < NIT; q++) {
         size_t p0 = (size_t)gys[q] * w + gxo;
+#if RC_RR_ABL == 2
+        A0[q] = make_float4(1.f + q, 0.5f * x, 0.25f, 0.125f * grp);
+        B0[q] = 0.1f * q;
+        (void)p0;
+#else
         A0[q] = RA0[p0];
         B0[q] = RB0[p0];
+#endif
     }
     float dx[NIT], dy[NIT];
     if constexpr (IN_MODE == 0) {
@@ -1337,6 +1349,15 @@ __global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
         }
     }
     __syncthreads();      // (drains the LDS-DMA)
+#if RC_RR_ABL == 1
+    if (a.w > 0) {        // timing-only build: the loads alone
+        float acc = LB[tid] + dx[0] + dy[NIT - 1];
+#pragma unroll
+        for (int q = 0; q < NIT; q++) acc += A0[q].x + A0[q].w + B0[q];
+        if (acc == 12345.678f) *(float*)fout = acc;
+        return;
+    }
+#endif
 
     // ---- M0 on the whole grid, in registers
     float m[NIT][5];

@@ -16,4 +16,4 @@ with Context(W, H) as ctx:
     for _ in range(10): ctx.farneback_clip(frames, flows, **P)
     ctx.profile_enable(False)
     rows = {r["kernel"]: r["total_ms"] * 1e3 / r["launches"] for r in ctx.profile_read()}
-    print(os.environ.get("RCFLOW_LIB", "default"), " ".join("%s %.1f" % (k, v) for k, v in rows.items() if k.startswith("polyexp")))
+    print(os.environ.get("RCFLOW_LIB", "default"), " ".join("%s %.1f" % (k, v) for k, v in rows.items() if k.startswith(("polyexp", "flow"))))
