@@ -207,6 +207,8 @@ def main():
     elif args.config == "c5":
         pass
     elif args.mode == "frame" or not args.clip_per_step:
+        if args.mode == "frame":
+            ctx.set_option("frame_overlap", 2)       # the clip is resident: every frame is complete when it is pushed
         ctx.stream_reset()
         ctx.push_clip(frames[0:1], flows, **params)          # primes the stream, no flow
     nstep = [0]

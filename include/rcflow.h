@@ -96,7 +96,9 @@ int rcflow_use_own_stream(rc_ctx* ctx, int stream);
  * "poly_tile_h" (32 | 48) rows per expansion block -- changes the per-tile DC and with it the last
  * bits of R; "poly_mfma" (0) vertical pass of the expansion on the matrix cores -- different
  * summation order, same tolerance; "overlap" (0) clip path on two streams; "hist_blocks" (0 = default)
- * cap on histogram blocks; "merge_small" (1) merged launches for calls of one or two frames; "fuse_pyr" (1)
+ * cap on histogram blocks; "frame_overlap" (0 | 1 | 2, default 1): the frame loop on two streams -- upload and expansion of
+ * frame t+1 beside the flow kernels of frame t; 1 = rcflow_push_frame_u8 only (the library owns the upload), 2 = also
+ * rcflow_push_frame_dev, the caller then guaranteeing that d_frame is complete when the call is made; "merge_small" (1) merged launches for calls of one or two frames; "fuse_pyr" (1)
  * pyramid scales 1 and 2 written by the scale-0 expansion launch (pyr_scale 0.5, exact half / quarter sizes);
  * "ablate" bit field selecting earlier kernel forms for A/B runs
  * (64 LDS-resident flow kernel, 128 / 256 / 512 other flow tiles, 2048 byte-wise u8 staging, 4096 earlier

@@ -47,7 +47,12 @@ struct RcBatchKey {
 
 struct RcSlot {
     hipStream_t own = nullptr, cur = nullptr;
-    hipStream_t aux = nullptr;  // second stream of the clip path (expansions beside flow kernels)
+    hipStream_t aux = nullptr;  // second stream: expansions beside flow kernels (clip path option "overlap"; frame loop)
+    // frame loop on two streams (rcflow_push_frame_dev): events in a small ring, reused in FIFO order
+    hipEvent_t fev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int fev_i = 0;
+    hipEvent_t flow_done[2] = {nullptr, nullptr};   // the flow launches of the last two pushes
+    int flow_done_i = 0;
     RcPlan plan;
     RcBuf kern;
     RcBuf I[RC_MAX_LEVELS], RA[RC_MAX_LEVELS], RB[RC_MAX_LEVELS];
@@ -89,6 +94,7 @@ struct rc_ctx {
     int fuse_iters = 1;
     int xcd_remap = 1;
     int poly_tile_h = 32;
+    int frame_overlap = 1;     // option "frame_overlap": frame loop with the expansion of frame t+1 on a second stream beside the flow kernels of frame t
     int merge_small = 1;       // option "merge_small": merged pyramid / expansion launches for calls of one or two frames
     int overlap = 0;           // option "overlap": clip path on two streams (measured: no gain, the grids fill the GPU)
     int poly_mfma = 0;          // option "poly_mfma": vertical pass of the expansion on the matrix cores (measured 25 % slower)

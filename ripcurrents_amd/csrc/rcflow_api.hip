@@ -215,6 +215,8 @@ static void slot_free(RcSlot& s) {
     for (auto& b : s.stage_f32) rc_buf_free(b);
     rc_buf_free(s.an.hist); rc_buf_free(s.an.hist_part); rc_buf_free(s.an.thr); rc_buf_free(s.an.acc);
     rc_buf_free(s.an.pt); rc_buf_free(s.an.dist); rc_buf_free(s.an.scratch); rc_buf_free(s.an.jet);
+    for (auto& e : s.fev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    for (auto& e : s.flow_done) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     if (s.own) (void)hipStreamDestroy(s.own);
     if (s.aux) (void)hipStreamDestroy(s.aux);
     s.aux = nullptr;
@@ -282,6 +284,9 @@ extern "C" int rcflow_set_option(rc_ctx* ctx, const char* name, int value) {
         ctx->hist_blocks = value;
     } else if (!strcmp(name, "overlap")) {
         ctx->overlap = value ? 1 : 0;
+    } else if (!strcmp(name, "frame_overlap")) {
+        if (value < 0 || value > 2) return RC_EINVAL;
+        ctx->frame_overlap = value;
     } else if (!strcmp(name, "merge_small")) {
         ctx->merge_small = value ? 1 : 0;
     } else if (!strcmp(name, "poly_mfma")) {
@@ -539,6 +544,7 @@ static int ensure_plan(rc_ctx* ctx, RcSlot& s, int w, int h, const rc_farneback_
         return RC_OK;
     rc_batch_graph_drop(s);
     RC_HIP(hipStreamSynchronize(s.cur));
+    if (s.aux) RC_HIP(hipStreamSynchronize(s.aux));
     pl.valid = false;
     pl.w = w; pl.h = h; pl.chunk = chunk; pl.nslots = nslots;
     memset(&pl.prm, 0, sizeof(pl.prm));
@@ -864,29 +870,81 @@ extern "C" int rcflow_stream_reset(rc_ctx* ctx, int stream) {
     return RC_OK;
 }
 
-extern "C" int rcflow_push_frame_dev(rc_ctx* ctx, int stream, const uint8_t* d_frame, size_t step, int w, int h,
-                                     float* d_flow, size_t flow_step, const rc_farneback_params* p) {
-    RcSlot* s = rc_slot(ctx, stream);
-    if (!s || !d_frame) { if (s) rc_set_error("null frame pointer"); return RC_EINVAL; }
-    if (step < (size_t)w) { rc_set_error("row step smaller than a row"); return RC_EINVAL; }
-    RC_HIP(hipSetDevice(ctx->device));
+// Frame loop on two streams.  The expansion of a frame depends only on the frame, the flow on the expansions of
+// this frame and the previous one: with `pre` set the caller-supplied step (an upload) and the expansion run on the
+// slot's second stream, beside the flow kernels of the PREVIOUS frame that the slot's stream may still be executing
+// (the calls are asynchronous, so a host that pushes ahead of the GPU gets the overlap; at one frame per call the
+// coarse scales' grids are smaller than the GPU and the two really run side by side).  Order kept by events:
+//   second stream: waits for the flow launches of the push before the previous one (every ring slot and frame buffer of
+//                  that age is free), [upload], expansion -> `expanded`
+//   slot's stream: waits for `expanded`, flow launches -> flow_done
+struct RcFrameAux {
+    const void* host_src; void* d_dst; size_t bytes;     // optional upload executed on the second stream
+    hipEvent_t after_upload;                             // recorded behind the upload (staging buffer free again)
+};
+
+static int push_frame_core(rc_ctx* ctx, RcSlot* s, int stream, const uint8_t* d_frame, size_t step, int w, int h,
+                           float* d_flow, size_t flow_step, const rc_farneback_params* p, bool two_streams,
+                           const RcFrameAux* up) {
     int was_valid = s->plan.valid;
     int rc = ensure_plan(ctx, *s, w, h, p, ctx->chunk);
     if (rc) return rc;
     if (!was_valid) s->primed = 0;
     s->batch_primed = 0;
+    (void)stream;
+    auto upload_on = [&](hipStream_t st) -> int {
+        if (!up) return RC_OK;
+        RC_HIP(hipMemcpyAsync(up->d_dst, up->host_src, up->bytes, hipMemcpyHostToDevice, st));
+        RC_HIP(hipEventRecord(up->after_upload, st));
+        return RC_OK;
+    };
     if (!s->primed) {
+        if ((rc = upload_on(s->cur))) return rc;
         if ((rc = expand_frames(ctx, *s, d_frame, 0, step, 1, 0))) return rc;
         s->primed = 1;
         s->cur_slot = 0;
         return 1;
     }
     if (!d_flow || flow_step < (size_t)w * 8) { rc_set_error("bad flow buffer"); return RC_EINVAL; }
-    int nxt = (s->cur_slot + 1) % s->plan.nslots;
+    const int nxt = (s->cur_slot + 1) % s->plan.nslots;
+    if (two_streams && !ctx->prof_on && s->plan.nslots >= 4) {
+        if (!s->aux) RC_HIP(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
+        for (auto& e : s->flow_done) if (!e) { RC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); RC_HIP(hipEventRecord(e, s->cur)); }
+        hipEvent_t& expanded = s->fev[s->fev_i];
+        s->fev_i = (s->fev_i + 1) % 8;
+        if (!expanded) RC_HIP(hipEventCreateWithFlags(&expanded, hipEventDisableTiming));
+        hipStream_t main_stream = s->cur;
+        const int older = s->flow_done_i;                  // written two pushes ago
+        RC_HIP(hipStreamWaitEvent(s->aux, s->flow_done[older], 0));
+        if ((rc = upload_on(s->aux))) return rc;
+        s->cur = s->aux;
+        rc = expand_frames(ctx, *s, d_frame, 0, step, 1, nxt);
+        s->cur = main_stream;
+        if (rc) return rc;
+        RC_HIP(hipEventRecord(expanded, s->aux));
+        RC_HIP(hipStreamWaitEvent(main_stream, expanded, 0));
+        if ((rc = compute_flows(ctx, *s, 1, s->cur_slot, d_flow, 0, flow_step))) return rc;
+        RC_HIP(hipEventRecord(s->flow_done[older], main_stream));
+        s->flow_done_i = older ^ 1;
+        s->cur_slot = nxt;
+        return RC_OK;
+    }
+    if ((rc = upload_on(s->cur))) return rc;
     if ((rc = expand_frames(ctx, *s, d_frame, 0, step, 1, nxt))) return rc;
     if ((rc = compute_flows(ctx, *s, 1, s->cur_slot, d_flow, 0, flow_step))) return rc;
     s->cur_slot = nxt;
     return RC_OK;
+}
+
+extern "C" int rcflow_push_frame_dev(rc_ctx* ctx, int stream, const uint8_t* d_frame, size_t step, int w, int h,
+                                     float* d_flow, size_t flow_step, const rc_farneback_params* p) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !d_frame) { if (s) rc_set_error("null frame pointer"); return RC_EINVAL; }
+    if (step < (size_t)w) { rc_set_error("row step smaller than a row"); return RC_EINVAL; }
+    RC_HIP(hipSetDevice(ctx->device));
+    // option "frame_overlap" = 2: the caller guarantees that d_frame is complete when the call is made (a resident clip, a
+    // producer it has synchronised) -- only then may the expansion start without waiting for the slot's stream
+    return push_frame_core(ctx, s, stream, d_frame, step, w, h, d_flow, flow_step, p, ctx->frame_overlap >= 2, nullptr);
 }
 
 // The reference's frame loop with HOST frames (ripcurrents.cpp:198-221: video.read -> resize -> cvtColor ->
@@ -922,10 +980,10 @@ extern "C" int rcflow_push_frame_u8(rc_ctx* ctx, int stream, const uint8_t* fram
     if (step == (size_t)w) memcpy(dst, frame, fb);
     else for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * w, frame + (size_t)y * step, w);
     uint8_t* d_frame = (uint8_t*)s->stage_u8.p + (size_t)i * fb;
-    RC_HIP(hipMemcpyAsync(d_frame, dst, fb, hipMemcpyHostToDevice, s->cur));
-    RC_HIP(hipEventRecord(s->pin_free[i], s->cur));
     s->pin_i = i ^ 1;
-    rc = rcflow_push_frame_dev(ctx, stream, d_frame, w, w, h, (float*)s->stage_flow.p, (size_t)w * 8, p);
+    // the upload belongs to the expansion's side of the two-stream frame loop (option "frame_overlap" >= 1)
+    RcFrameAux up = {dst, d_frame, fb, s->pin_free[i]};
+    rc = push_frame_core(ctx, s, stream, d_frame, w, w, h, (float*)s->stage_flow.p, (size_t)w * 8, p, ctx->frame_overlap >= 1, &up);
     if (rc == RC_OK) { s->flow_w = w; s->flow_h = h; }
     else if (rc == 1) { s->flow_w = s->flow_h = 0; }
     return rc;

@@ -77,3 +77,42 @@ def test_allreduce_is_identity_without_a_process_group():
     assert torch.equal(g, w) and g.data_ptr() != w.data_ptr()
     with pytest.raises(ValueError):
         allreduce_hist_words(torch.zeros(5, dtype=torch.int32))
+
+
+class _FakeCtx:
+    """Records what distributed.init_comm asks of a context (no GPU in this tier)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def comm_unique_id(self):
+        self.calls.append("unique_id")
+        return bytes(range(128))
+
+    def comm_init(self, rank, world, unique_id=None):
+        self.calls.append(("init", rank, world, unique_id))
+
+
+def _init_comm_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ripcurrents_amd.distributed import init_comm
+    ctx = _FakeCtx()
+    assert init_comm(ctx) == (rank, world)
+    # only rank 0 creates the RCCL id; every rank joins with the SAME 128 bytes
+    assert ("unique_id" in ctx.calls) == (rank == 0)
+    assert ctx.calls[-1] == ("init", rank, world, bytes(range(128)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c_abi_communicator_bootstrap_over_torch_distributed(tmp_path):
+    """distributed.init_comm: the 128-byte RCCL id travels from rank 0 to the others over torch.distributed (the
+    out-of-band channel of rcflow_comm_init); without a process group the world is one rank."""
+    sys.path.insert(0, ROOT)
+    from ripcurrents_amd.distributed import init_comm
+    solo = _FakeCtx()
+    assert init_comm(solo) == (0, 1) and solo.calls == [("init", 0, 1, None)]
+    world, port = 2, 29750 + os.getpid() % 200
+    mp.spawn(_init_comm_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)

@@ -683,3 +683,30 @@ def test_profile_buckets_carry_the_reference_names(ctx):
     assert list(b) == ["farneback", "polar", "threshold", "overlay", "erosion", "codec", "stream"]
     assert b["farneback"] > 0 and b["threshold"] > 0 and b["stream"] > 0 and b["polar"] == 0 and b["codec"] == 0
     ctx.profile_reset()
+
+
+def test_frame_loop_on_two_streams_same_bits(ctx):
+    """Option frame_overlap = 2: rcflow_push_frame_dev with the expansion of frame t + 1 on the slot's second stream
+    beside the flow kernels of frame t (resident frames: complete when pushed).  Same flow fields as the one-stream
+    loop, also when the caller races ahead of the GPU for many frames and across a ring wrap (chunk 3 -> 4 slots)."""
+    w, h, T = 320, 240, 14
+    p = dict(pyr_scale=0.5, levels=2, winsize=3, iterations=2, poly_n=15, poly_sigma=1.2, flags=0)
+    d = torch.as_tensor(synth.surf_clip(w, h, T, seed=21)).cuda()
+    ref = ctx.farneback_clip(d, **p).cpu().numpy()
+    torch.cuda.synchronize()
+    for chunk in (32, 3):
+        ctx.set_option("chunk", chunk)
+        ctx.set_option("frame_overlap", 2)
+        try:
+            ctx.stream_reset()
+            outs = torch.empty((T - 1, h, w, 2), dtype=torch.float32, device="cuda")
+            assert ctx.push_frame(d[0], **p) is None
+            for t in range(1, T):                       # no synchronisation inside the loop
+                ctx.push_frame(d[t], outs[t - 1], **p)
+            ctx.sync()
+            torch.cuda.synchronize()
+            assert np.array_equal(outs.cpu().numpy(), ref)
+        finally:
+            ctx.set_option("frame_overlap", 1)
+            ctx.set_option("chunk", 32)
+    ctx.stream_reset()
