@@ -710,3 +710,36 @@ def test_frame_loop_on_two_streams_same_bits(ctx):
             ctx.set_option("frame_overlap", 1)
             ctx.set_option("chunk", 32)
     ctx.stream_reset()
+
+
+def test_host_frame_loop_argument_and_state_errors(ctx):
+    """Error behaviour of the host-frame entry points: bad arguments, oversize frames, reading a flow that does not
+    exist yet, a size change in mid-stream (re-primes, like the device-pointer loop)."""
+    import ctypes as C
+    from ripcurrents_amd import RcflowError
+    from ripcurrents_amd._lib import FarnebackParams
+    lib, h = ctx._lib, ctx._h
+    p = FarnebackParams(0.5, 2, 3, 2, 15, 1.2, 0)
+    a = np.zeros((64, 80), np.uint8)
+    assert lib.rcflow_push_frame_u8(h, 0, None, 80, 80, 64, C.byref(p)) == -1
+    assert lib.rcflow_push_frame_u8(h, 0, a.ctypes.data, 40, 80, 64, C.byref(p)) == -1          # step < width
+    assert lib.rcflow_push_frame_u8(h, 99, a.ctypes.data, 80, 80, 64, C.byref(p)) == -1         # no such slot
+    big = np.zeros((2200, 4000), np.uint8)
+    assert lib.rcflow_push_frame_u8(h, 0, big.ctypes.data, 4000, 4000, 2200, C.byref(p)) == -5  # RC_ESIZE
+    ctx.stream_reset()
+    with pytest.raises(RcflowError) as e:
+        ctx.stream_flow_read(80, 64)
+    assert e.value.code == -6
+    clip = synth.surf_clip(160, 120, 3, seed=1)
+    small = synth.surf_clip(96, 80, 2, seed=2)
+    pk = dict(pyr_scale=0.5, levels=2, winsize=3, iterations=2, poly_n=15, poly_sigma=1.2, flags=0)
+    assert ctx.push_frame_host(clip[0], **pk) is None
+    assert ctx.push_frame_host(clip[1], **pk) is not None
+    assert ctx.push_frame_host(small[0], **pk) is None                                           # other size: primes again
+    with pytest.raises(RcflowError):
+        ctx.stream_flow_read(96, 80)
+    f = ctx.push_frame_host(small[1], **pk)
+    ref = ctx.calcOpticalFlowFarneback(small[0], small[1], None, **pk)
+    ctx.sync()
+    assert np.array_equal(f.cpu().numpy(), ref)
+    ctx.stream_reset()
