@@ -17,8 +17,8 @@
 //   k_exact_flow_init (resize * 1/pyr_scale | zeros)  ->  flow_k
 //   k_exact_matrices  ->  M (5 planes)
 //   Gaussian window: k_exact_gauss_v -> V (float), k_exact_gauss_h_solve -> flow_k
-//   box window:      k_exact_box_vscan -> V (double running column sums, sequential in y like
-//                    upstream's vsum), k_exact_box_hscan_solve (sequential in x) -> flow_k
+//   box window:      k_exact_box_vscan -> V (double running column sums, sequential in y like upstream's vsum),
+//                    k_exact_box_hscan (running row sums, sequential in x, in place), k_exact_box_solve -> flow_k
 
 #include "rc_device.h"
 
@@ -326,6 +326,7 @@ __global__ __launch_bounds__(256) void k_exact_gauss_h_solve(RcExactArgs a) {
 // ------------------------------------------------------------------ FarnebackUpdateFlow_Blur
 // upstream's running column sums: double accumulators fed with FLOAT differences of rows, so the
 // rounding of every (srow1 - srow0) is carried down the column; replayed sequentially per column.
+// The loads do not depend on the running sum: eight rows of them are issued ahead of the eight dependent additions.
 __global__ __launch_bounds__(64) void k_exact_box_vscan(RcExactArgs a) {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int z = blockIdx.y / 5, c = blockIdx.y - z * 5;
@@ -335,32 +336,62 @@ __global__ __launch_bounds__(64) void k_exact_box_vscan(RcExactArgs a) {
     double* V = (double*)a.V + ((size_t)z * 5 + c) * a.n + x;
     double vsum = M[0] * (m + 2);                          // float product
     for (int y = 1; y < m; y++) vsum += M[(size_t)min(y, h - 1) * w];
-    for (int y = 0; y < h; y++) {
-        const float s0 = M[(size_t)max(y - m - 1, 0) * w], s1 = M[(size_t)min(y + m, h - 1) * w];
-        vsum += s1 - s0;
-        V[(size_t)y * w] = vsum;
+    constexpr int U = 8;
+    for (int y0 = 0; y0 < h; y0 += U) {
+        float d[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int y = min(y0 + u, h - 1);
+            d[u] = M[(size_t)min(y + m, h - 1) * w] - M[(size_t)max(y - m - 1, 0) * w];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (y0 + u < h) {
+                vsum += d[u];
+                V[(size_t)(y0 + u) * w] = vsum;
+            }
+        }
     }
 }
-// one thread per row: the running row sums (double), scale, solve
-__global__ __launch_bounds__(64) void k_exact_box_hscan_solve(RcExactArgs a) {
-    const int y = blockIdx.x * 64 + threadIdx.x, z = blockIdx.y;
+// running row sums (double), one thread per (row, channel): G(x) = G(x - 1) + V(x + m) - V(x - m - 1), replicated
+// borders; eight steps of loads ahead of the eight dependent additions.  (Moving V in and G out through LDS tiles so
+// that global memory sees whole row segments was measured slower with one wave per block: 822 vs 544 us per 1080p pair.)
+__global__ __launch_bounds__(64) void k_exact_box_hscan(RcExactArgs a) {
+    const int y = blockIdx.x * 64 + threadIdx.x;
+    const int z = blockIdx.y / 5, c = blockIdx.y - z * 5;
     if (y >= a.h) return;
     const int m = a.win.m, w = a.w;
-    const double* V[5];
-    double g[5];
-    for (int c = 0; c < 5; c++) {
-        V[c] = (const double*)a.V + ((size_t)z * 5 + c) * a.n + (size_t)y * w;
-        g[c] = V[c][0] * (m + 2);
-        for (int x = 1; x < m; x++) g[c] += V[c][min(x, w - 1)];
+    const double* V = (const double*)a.V + ((size_t)z * 5 + c) * a.n + (size_t)y * w;
+    double* G = (double*)a.G + ((size_t)z * 5 + c) * a.n + (size_t)y * w;
+    double g = V[0] * (m + 2);
+    for (int x = 1; x < m; x++) g += V[min(x, w - 1)];
+    constexpr int U = 8;
+    for (int x0 = 0; x0 < w; x0 += U) {
+        double vn[U], vo[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int x = min(x0 + u, w - 1);
+            vn[u] = V[min(x + m, w - 1)];
+            vo[u] = V[max(x - m - 1, 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (x0 + u < w) {
+                g += vn[u] - vo[u];
+                G[x0 + u] = g;
+            }
+        }
     }
+}
+// scale + solve, one thread per pixel
+__global__ __launch_bounds__(256) void k_exact_box_solve(RcExactArgs a) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
+    if (x >= a.w || y >= a.h) return;
+    const double* G = (const double*)a.G + (size_t)z * 5 * a.n + (size_t)y * a.w + x;
     const double scale = a.win.box_scale;
-    for (int x = 0; x < w; x++) {
-        const int xa = min(x + m, w - 1), xb = max(x - m - 1, 0);
-        for (int c = 0; c < 5; c++) g[c] += V[c][xa] - V[c][xb];
-        const float2 f = rc_exact_solve(g[0] * scale, g[1] * scale, g[2] * scale, g[3] * scale, g[4] * scale);
-        if (a.out) *(float2*)(a.out + (size_t)z * a.out_pair_stride + (size_t)y * a.out_step + (size_t)x * 8) = f;
-        else a.flow[(size_t)z * a.n + (size_t)y * w + x] = f;
-    }
+    const float2 f = rc_exact_solve(G[0] * scale, G[a.n] * scale, G[2 * a.n] * scale, G[3 * a.n] * scale, G[4 * a.n] * scale);
+    if (a.out) *(float2*)(a.out + (size_t)z * a.out_pair_stride + (size_t)y * a.out_step + (size_t)x * 8) = f;
+    else a.flow[(size_t)z * a.n + (size_t)y * a.w + x] = f;
 }
 
 // ------------------------------------------------------------------ launchers
@@ -376,6 +407,7 @@ void rc_launch_exact_window_solve(const RcExactArgs& a, int pairs, hipStream_t s
         hipLaunchKernelGGL(k_exact_gauss_h_solve, dim3((a.w + 63) / 64, (a.h + 3) / 4, pairs), dim3(256), 0, s, a);
     } else {
         hipLaunchKernelGGL(k_exact_box_vscan, dim3((a.w + 63) / 64, pairs * 5), dim3(64), 0, s, a);
-        hipLaunchKernelGGL(k_exact_box_hscan_solve, dim3((a.h + 63) / 64, pairs), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_exact_box_hscan, dim3((a.h + 63) / 64, pairs * 5), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_exact_box_solve, dim3((a.w + 63) / 64, (a.h + 3) / 4, pairs), dim3(256), 0, s, a);
     }
 }

@@ -159,6 +159,7 @@ struct RcExactArgs {
     float2* flow;             // [pairs][h][w]
     float* M;                 // [pairs][5][h][w]
     void* V;                  // [pairs][5][h][w]: float (Gaussian window) / double (box window)
+    void* G;                  // box window: [pairs][5][h][w] double running row sums
     char* out;                // last iteration of scale 0: the caller's buffer (else null -> flow)
     size_t out_step, out_pair_stride;
     RcWindow win;

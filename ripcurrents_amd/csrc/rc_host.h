@@ -58,7 +58,7 @@ struct RcSlot {
     RcBuf I[RC_MAX_LEVELS], RA[RC_MAX_LEVELS], RB[RC_MAX_LEVELS];
     RcBuf FA[RC_MAX_LEVELS], FB[RC_MAX_LEVELS];
     RcBuf stage_u8, stage_flow, stage_f32[4];
-    RcBuf exM, exV;            // option "exact": matrix planes and window column sums
+    RcBuf exM, exV, exG;       // option "exact": matrix planes, window column sums, window row sums (box)
     // host-pointer frame loop (rcflow_push_frame_u8): two page-locked staging frames, an event per frame that
     // fires when its upload has left the staging buffer, two device frames (stage_u8) and the resident flow
     void* pin[2] = {nullptr, nullptr};
