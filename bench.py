@@ -83,7 +83,7 @@ def main():
                     help="bracket every kernel of every Nth timed step with HIP events (1 = every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roof", action="store_true", help="skip the measured memory roof (read/fill/copy microbench)")
-    ap.add_argument("--cpu-pairs", type=int, default=6)
+    ap.add_argument("--cpu-pairs", type=int, default=16)
     ap.add_argument("--collective", choices=["torch", "rccl"], default="torch",
                     help="N>1: torch.distributed all_reduce (default) or the library's C-ABI collective "
                          "(rcflow_allreduce_hist over librccl)")

@@ -29,6 +29,12 @@ def main():
     p2 = dict(p, flags=256, winsize=10, iters=3)
     flow2 = oracle.farneback(clip[0], clip[1], **p2)
     np.savez_compressed(os.path.join(HERE, "farneback_main1119_96x80.npz"), prev=clip[0], next=clip[1], flow=flow2, **p2)
+    # main.cpp:264 (Gaussian winsize 3): the library's default path for it is upstream's operation order, so this one
+    # must be reproduced bit for bit by the HIP path; the determinants of the final solves travel with it
+    p3 = dict(p, flags=256)
+    flow3, det_last, det_min = oracle.farneback_diag(clip[0], clip[1], **p3)
+    np.savez_compressed(os.path.join(HERE, "farneback_main264_96x80.npz"), prev=clip[0], next=clip[1], flow=flow3,
+                        det_last=det_last.astype(np.float32), det_min=det_min, **p3)
     st = oracle.HistState()
     oracle.create_histogram(oracle.flow_to_polar(flow), st)
     np.savez_compressed(os.path.join(HERE, "histogram_96x80.npz"), flow=flow, hist=st.hist, hist2d=st.hist2d,

@@ -582,6 +582,19 @@ def test_against_committed_golden_fixtures(ctx):
                                            g["poly_sigma"].item(), g["flags"].item())
         st = _report("golden " + name, got, g["flow"])
         assert st["frac_1e3"] >= minfrac
+    # main.cpp:264's parameters: the default path is exact -> the committed vector bit for bit; and every parameter set
+    # through option exact = 1
+    g = np.load(os.path.join(gold, "farneback_main264_96x80.npz"))
+    args = [g[k].item() for k in ("pyr_scale", "levels", "winsize", "iters", "poly_n", "poly_sigma", "flags")]
+    assert np.array_equal(ctx.calcOpticalFlowFarneback(g["prev"], g["next"], None, *args), g["flow"])
+    ctx.set_option("exact", 1)
+    try:
+        for name in ("farneback_rc215_96x80.npz", "farneback_main1119_96x80.npz"):
+            g = np.load(os.path.join(gold, name))
+            args = [g[k].item() for k in ("pyr_scale", "levels", "winsize", "iters", "poly_n", "poly_sigma", "flags")]
+            assert np.array_equal(ctx.calcOpticalFlowFarneback(g["prev"], g["next"], None, *args), g["flow"]), name
+    finally:
+        ctx.set_option("exact", -1)
     from ripcurrents_amd.api import HistState
     h = np.load(os.path.join(gold, "histogram_96x80.npz"))
     st = HistState()
