@@ -245,3 +245,20 @@ def test_fast_path_against_the_exact_path_over_whole_clips(ctx, name, p, size, T
         assert p999 <= 1e-3, (name, t, p999)
         assert int(big.sum()) <= 1e-5 * e.numel() and not bool((big & inner).any()), (name, t, int(big.sum()))
     print("\n[fast vs exact, every field] %s: %s" % (name, worst))
+
+
+def test_exact_strided_buffers_and_two_slots(exact, orc):
+    """cv::Mat-style row steps on inputs and output through the exact path (box and Gaussian), on the second
+    stream slot as well."""
+    clip = synth.surf_clip(300, 200, 2, seed=2)
+    big = np.zeros((2, 200, 352), np.uint8)
+    big[:, :, :300] = clip
+    for p in (RC215, MAIN264):
+        ref = orc.farneback(clip[0], clip[1], **_o(p))
+        out = np.full((200, 320, 2), np.nan, np.float32)
+        exact.calcOpticalFlowFarneback(big[0, :, :300], big[1, :, :300], out[:, :300], **p)
+        assert np.array_equal(out[:, :300], ref) and np.isnan(out[:, 300:]).all()
+        d = torch.as_tensor(clip).cuda()
+        got = exact.calcOpticalFlowFarneback(d[0], d[1], None, stream=1, **p)
+        exact.sync(1)
+        assert np.array_equal(got.cpu().numpy(), ref)
