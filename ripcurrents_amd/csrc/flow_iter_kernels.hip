@@ -18,6 +18,8 @@
 // Compile-time tile/window instantiations cover the reference's window sizes (3, 5, 10,
 // 20: SURVEY.md section 2.2); any other winsize takes the generic runtime kernel.
 
+#include <cstdlib>
+
 #include "rc_device.h"
 
 #define RC_ITER_BATCH 3
@@ -1427,6 +1429,7 @@ static void launch_rr_t(RcIterArgs a, int pairs, hipStream_t s) {
     a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
     constexpr int WN = (MW + 2 * D + RC_RR_WPAD) * (MH + 2 * D), WNP = (WN + 63) & ~63;
     size_t lds = sizeof(float) * (5 * WNP + NG * 2 * 5 * MW);
+    if (const char* pad = getenv("RC_RR_LDS_PAD_KB")) lds += (size_t)atoi(pad) * 1024;      // occupancy experiment: fewer blocks per CU
     RC_ALLOW_LDS((k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB, MW, NG>), lds);
     hipLaunchKernelGGL((k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB, MW, NG>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(NG * MW), lds, s, a);
 }
