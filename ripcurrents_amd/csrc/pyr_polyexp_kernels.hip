@@ -437,7 +437,7 @@ void rc_launch_pyr(const RcPyrArgs& a, int frames, size_t lds, hipStream_t s) {
 // float image never exists in HBM.
 #define RC_POLY_BLOCK 512
 #ifndef RC_POLY_ABL
-#define RC_POLY_ABL 0     // timing-only ablations (never in the product): 1 = no R stores, 2 = the stores alone, 3 = staging + blur + pyramid alone
+#define RC_POLY_ABL 0     // timing-only ablations (never in the product): 1 = no R stores, 2 = the stores alone, 3 = staging + blur + pyramid alone, 4 = no staging loads
 #endif
 #ifndef RC_POLY_B128
 #define RC_POLY_B128 1    // horizontal pass: window reads as forced ds_read_b128 (0 = the compiler's choice)
@@ -563,8 +563,11 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
     constexpr int INW = TW + 2 * RP, INH = TH + 2 * R;
     constexpr int NV = 4 + 2 * RP;
     constexpr int NDW = (INW + 8) / 4, UBW = 4 * NDW, UBH = INH + 2;   // u8 staging: pitch UBW bytes
-#ifdef RC_STAMPS   // diagnostic build only: s_memtime phase stamps of every 61st tile of frame 0 (scripts/r2/poly_stamps.py)
-    const bool stamp_on = a.stamps && threadIdx.x == 0 && z == 0 && ((bx + by * 30) % 61) == 0;
+#ifdef RC_STAMPS   // diagnostic build only: s_memtime phase stamps of every 61st tile of one frame of the batch (scripts/r2/poly_stamps.py)
+#ifndef RC_STAMP_FRAME
+#define RC_STAMP_FRAME 16      // a frame in the middle of a 33-frame launch: steady state, not the first generation of blocks
+#endif
+    const bool stamp_on = a.stamps && threadIdx.x == 0 && z == RC_STAMP_FRAME && ((bx + by * 30) % 61) == 0;
     long long* stp = a.stamps ? a.stamps + (size_t)((bx + by * 30) / 61) * 8 : nullptr;
 #define RC_PSTAMP(i) if (stamp_on) stp[i] = __builtin_amdgcn_s_memtime()
 #else
@@ -603,7 +606,12 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
                 int idx = tid + q * RC_POLY_BLOCK;
                 int i = idx / NDW, j = idx - i * NDW;
                 int sy = rc_reflect101(PYR ? ylo + i : min(ylo + i, h), h);
+#if RC_POLY_ABL == 4      // timing-only build: no staging loads (how much of the kernel is the wait for them? 505 -> 470 us)
+                v[q] = 0x01020304u * (tid + q);
+                (void)sy;
+#else
                 v[q] = idx < UBH * NDW ? *(const unsigned int*)(src + (size_t)sy * a.src8_step + xs + 4 * j) : 0u;
+#endif
             }
 #pragma unroll
             for (int q = 0; q < NLD; q++) {

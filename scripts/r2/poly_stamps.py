@@ -11,7 +11,6 @@ P = dict(pyr_scale=0.5, levels=2, winsize=3, iterations=2, poly_n=15, poly_sigma
 frames = synth.surf_clip(W, H, NP + 1, device=torch.device("cuda"))
 flows = torch.empty((NP, H, W, 2), dtype=torch.float32, device="cuda")
 with Context(W, H) as ctx:
-    ctx.set_option("poly_persist", 0)
     for _ in range(3): ctx.farneback_clip(frames, flows, **P)
     ctx.set_option("stamps", 1)
     for _ in range(2): ctx.farneback_clip(frames, flows, **P)
@@ -22,9 +21,9 @@ with Context(W, H) as ctx:
     assert lib.rcflow_debug_read_stamps(ctx._h, buf, n) == 0
 s = np.array(buf[:]).reshape(-1, 8)
 s = s[(s[:, 0] > 0) & (s[:, 7] > 0)]
-d = np.diff(s, axis=1).astype(np.float64) * 10
+d = np.diff(s, axis=1).astype(np.float64)
 names = ["wait loads + stage + barrier", "fused pyramid phase", "blur -> tin (+barrier)", "horizontal pass + barrier", "vertical pass", "issue stores", "stores acknowledged"]
 print(os.environ.get("RCFLOW_LIB", "default"), "blocks sampled", len(s))
 for i, nm in enumerate(names):
-    print("  %-32s median %7.0f ns   p90 %7.0f ns" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 90)))
-print("  %-32s median %7.0f ns" % ("block total (to stores issued)", np.median(s[:, 6] - s[:, 0]) * 10))
+    print("  %-32s median %7.0f cycles   p90 %7.0f cycles" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 90)))
+print("  %-32s median %7.0f cycles" % ("block total (to stores issued)", np.median(s[:, 6] - s[:, 0])))
