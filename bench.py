@@ -60,7 +60,7 @@ def pmc_traffic(kernel, args):
     try:
         d = json.load(open(os.path.join(ROOT, PMC_FILE)))
         chunk = args.chunk or 32
-        if min(chunk, args.pairs) != d["pairs_per_launch"] or args.gaussian:
+        if min(chunk, args.pairs) != d["pairs_per_launch"] or args.gaussian or args.exact:
             return None, None, None
         src = "%s (%s; commit %s)" % (PMC_FILE, d.get("collected", "separate --pmc passes"), d.get("commit", "?"))
         return d["kernels"][kernel]["traffic_bytes_per_launch"], d.get("pipeline_bytes_per_field"), src
@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--sync-collective", action="store_true", help="N>1: all-reduce and thresholds inside the step (no one-step pipelining)")
     ap.add_argument("--clip-per-step", action="store_true", help="every step is an independent clip of pairs + 1 frames (pairs + 1 expansions)")
     ap.add_argument("--gaussian", action="store_true", help="main.cpp:264 variant (flags=256)")
+    ap.add_argument("--exact", action="store_true",
+                    help="option exact = 1: the HIP path in upstream's CPU operation order (bit-identical to the oracle); "
+                         "own metric name, headline false")
     ap.add_argument("--config", choices=["c1", "c2", "c3", "c5"], default="c2",
                     help="BASELINE.json configuration: c2 (default, the headline) 1080p 3 scales; c1 640x480 translating texture; "
                          "c3 3840x2160 5 scales (levels=4) + 250 seed streamlines and 5 streaklines per field; c5 16 lock-step 1080p "
@@ -155,6 +158,8 @@ def main():
         frames = synth.surf_clip(W, H, T, seed=1234 + rank, device=dev)      # generated in HBM
     flows = torch.empty((args.pairs, H, W, 2), dtype=torch.float32, device=dev)
     ctx = Context(W, H, device=local_rank, streams=1)
+    if args.exact:
+        ctx.set_option("exact", 1)
     if args.chunk:
         ctx.set_option("chunk", args.chunk)
     ctx.analysis_reset(W, H)
@@ -341,8 +346,10 @@ def main():
         cfg_names = {"c2": "@1080p", "c1": "@640x480 (config 1, translating texture)", "c3": "@3840x2160, 5 scales + streamline / streakline advection (config 3)",
                      "c5": "@1080p, 16 lock-step streams per GPU, hipGraph replay (config 5)"}
         out = {
-            "metric": "frames/sec dense Farneback flow " + cfg_names[args.config] + mode_names[args.mode],
-            "bench_config": args.config, "mode": args.mode, "headline": args.mode == "clip" and args.config == "c2",
+            "metric": "frames/sec dense Farneback flow " + cfg_names[args.config] + mode_names[args.mode]
+                      + (" [option exact: upstream's operation order, bit-identical to the CPU oracle]" if args.exact else ""),
+            "bench_config": args.config, "mode": args.mode, "exact": bool(args.exact),
+            "headline": args.mode == "clip" and args.config == "c2" and not args.exact and not args.gaussian,
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -380,9 +387,11 @@ def main():
                                "traffic": traffic, "traffic_source": src,
                                "avg_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
                                "alg_bytes_per_launch": dom["alg_bytes"] / dom["launches"],
-                               "alg_bytes_def": "compulsory bytes of the launch as built: R0 20 + R1 20 + coarse flow 2 + "
-                                                "flow out 8 = 50 B per pixel x 2 073 600 px x pairs per launch "
-                                                "(M never exists in HBM, two iterations per launch)",
+                               "alg_bytes_def": ("bytes of the launches of this kind as staged through HBM (exact path: M, the "
+                                                 "column sums and the flow between its kernels)" if args.exact else
+                                                 "compulsory bytes of the launch as built: R0 20 + R1 20 + coarse flow 2 + "
+                                                 "flow out 8 = 50 B per pixel x 2 073 600 px x pairs per launch "
+                                                 "(M never exists in HBM, two iterations per launch)"),
                                "frac_of_traffic": round(traffic / secs * dom["launches"] / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                                "survey_model_equivalent": {"bytes_per_launch": dom["model_bytes"] / dom["launches"],
                                                            "GBs": round(dom["model_bytes"] / secs / 1e9, 1),

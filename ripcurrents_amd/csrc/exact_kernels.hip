@@ -394,6 +394,122 @@ __global__ __launch_bounds__(256) void k_exact_box_solve(RcExactArgs a) {
     else a.flow[(size_t)z * a.n + (size_t)y * a.w + x] = f;
 }
 
+// ---- box windows of radius 1 and 2 (winsize 3: ripcurrents.cpp:215; winsize 5: the Android fork): the same two
+// sequential scans with every global access coalesced.  The column scan hands its running sums over TRANSPOSED
+// (V^T[channel][x][y], rows padded to a multiple of 16), through a 64 x 16 LDS tile per wave, so that the row scan --
+// one lane per image row -- reads 512 contiguous bytes per step.  The row scan keeps all five channels of its row,
+// solves the 2 x 2 system in place (G never goes to memory) and writes the flow through a second LDS transposition
+// as whole 128-byte row segments.  The next sixteen steps' column sums are loaded while the current sixteen are
+// consumed; what a step subtracts is what an earlier step added, kept in registers.
+template <int MM>
+__global__ __launch_bounds__(64) void k_exact_box_vscan_t(RcExactArgs a, int hp) {
+    __shared__ double T[64 * 17];
+    const int lane = threadIdx.x;
+    const int x0 = blockIdx.x * 64, x = min(x0 + lane, a.w - 1);
+    const int z = blockIdx.y / 5, c = blockIdx.y - z * 5;
+    constexpr int m = MM;
+    const int h = a.h, w = a.w;
+    const float* M = a.M + ((size_t)z * 5 + c) * a.n + x;
+    double* VT = (double*)a.V + ((size_t)z * 5 + c) * (size_t)w * hp;
+    double vsum = M[0] * (m + 2);                          // float product
+    for (int y = 1; y < m; y++) vsum += M[(size_t)min(y, h - 1) * w];
+    for (int y0 = 0; y0 < h; y0 += 16) {
+        float d[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int y = min(y0 + u, h - 1);
+            d[u] = M[(size_t)min(y + m, h - 1) * w] - M[(size_t)max(y - m - 1, 0) * w];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            vsum += d[u];                                  // (rows past the image: values nobody reads)
+            T[lane * 17 + u] = vsum;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int xl = i * 8 + (lane >> 3), yy = (lane & 7) * 2;
+            const double v0 = T[xl * 17 + yy], v1 = T[xl * 17 + yy + 1];
+            if (x0 + xl < w) *(double2*)(VT + (size_t)(x0 + xl) * hp + y0 + yy) = make_double2(v0, v1);
+        }
+        __syncthreads();
+    }
+}
+
+template <int MM>
+__global__ __launch_bounds__(64) void k_exact_box_hsolve_t(RcExactArgs a, int hp) {
+    constexpr int m = MM, L = 2 * MM + 1, U = 16;
+    static_assert(L <= U, "the ring is refilled from one block of steps");
+    __shared__ float2 T[64 * 17];
+    const int lane = threadIdx.x;
+    const int y0 = blockIdx.x * 64, y = min(y0 + lane, a.h - 1);
+    const int z = blockIdx.y;
+    const int w = a.w;
+    const double scale = a.win.box_scale;
+    const double* VT = (const double*)a.V + (size_t)z * 5 * (size_t)w * hp + y;
+    const size_t cs = (size_t)w * hp;                      // channel stride
+    // ring[c][j] = V(x - m - 1 + j) before step x, j = 0 .. 2m  (clamped columns); g = upstream's initial sums
+    double ring[5][L], g[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+#pragma unroll
+        for (int j = 0; j < L; j++) ring[c][j] = VT[c * cs + (size_t)rc_clampi(j - m - 1, 0, w - 1) * hp];
+        const double v0 = VT[c * cs];
+        g[c] = v0 * (m + 2);
+        for (int xx = 1; xx < m; xx++) g[c] += VT[c * cs + (size_t)min(xx, w - 1) * hp];
+    }
+    double nv[2][U][5];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int c = 0; c < 5; c++) nv[0][u][c] = VT[c * cs + (size_t)min(u + m, w - 1) * hp];
+    char* outp;
+    size_t ostep;
+    if (a.out) { outp = a.out + (size_t)z * a.out_pair_stride; ostep = a.out_step; }
+    else { outp = (char*)(a.flow + (size_t)z * a.n); ostep = (size_t)w * 8; }
+
+    auto block = [&](const double (&cur)[U][5], double (&nxt)[U][5], int xb) {
+        // the next block's column sums, in flight while this block is consumed
+        if (xb + U < w) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int c = 0; c < 5; c++) nxt[u][c] = VT[c * cs + (size_t)min(xb + U + u + m, w - 1) * hp];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            double gs[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const double vold = u >= L ? cur[u - L][c] : ring[c][u];
+                g[c] += cur[u][c] - vold;
+                gs[c] = g[c] * scale;
+            }
+            T[lane * 17 + u] = rc_exact_solve(gs[0], gs[1], gs[2], gs[3], gs[4]);
+        }
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+#pragma unroll
+            for (int j = 0; j < L; j++) ring[c][j] = cur[U - L + j][c];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int yl = i * 8 + (lane >> 3), xx = (lane & 7) * 2;
+            const float2 f0 = T[yl * 17 + xx], f1 = T[yl * 17 + xx + 1];
+            char* o = outp + (size_t)(y0 + yl) * ostep + (size_t)(xb + xx) * 8;
+            if (y0 + yl < a.h) {
+                if (xb + xx + 1 < w) *(float4*)o = make_float4(f0.x, f0.y, f1.x, f1.y);
+                else if (xb + xx < w) *(float2*)o = f0;
+            }
+        }
+        __syncthreads();
+    };
+    for (int xb = 0; xb < w; xb += 2 * U) {
+        block(nv[0], nv[1], xb);
+        if (xb + U < w) block(nv[1], nv[0], xb + U);
+    }
+}
+
 // ------------------------------------------------------------------ launchers
 void rc_launch_exact_flow_init(const RcExactArgs& a, int pairs, hipStream_t s) {
     hipLaunchKernelGGL(k_exact_flow_init, dim3((a.w + 63) / 64, (a.h + 3) / 4, pairs), dim3(256), 0, s, a);
@@ -406,6 +522,19 @@ void rc_launch_exact_window_solve(const RcExactArgs& a, int pairs, hipStream_t s
         hipLaunchKernelGGL(k_exact_gauss_v, dim3((a.w + 63) / 64, (a.h + 3) / 4, pairs * 5), dim3(256), 0, s, a);
         hipLaunchKernelGGL(k_exact_gauss_h_solve, dim3((a.w + 63) / 64, (a.h + 3) / 4, pairs), dim3(256), 0, s, a);
     } else {
+        // (the flow rows are written as float4 pairs: 16-byte aligned rows only; any other shape takes the plain scans)
+        const bool al16 = a.out ? ((((size_t)a.out) | a.out_step | a.out_pair_stride) & 15) == 0 : (a.w % 2) == 0;
+        const int hp = (a.h + 15) & ~15;
+        if ((a.win.m == 1 || a.win.m == 2) && al16 && !a.plain_scans) {
+            if (a.win.m == 1) {
+                hipLaunchKernelGGL(k_exact_box_vscan_t<1>, dim3((a.w + 63) / 64, pairs * 5), dim3(64), 0, s, a, hp);
+                hipLaunchKernelGGL(k_exact_box_hsolve_t<1>, dim3((a.h + 63) / 64, pairs), dim3(64), 0, s, a, hp);
+            } else {
+                hipLaunchKernelGGL(k_exact_box_vscan_t<2>, dim3((a.w + 63) / 64, pairs * 5), dim3(64), 0, s, a, hp);
+                hipLaunchKernelGGL(k_exact_box_hsolve_t<2>, dim3((a.h + 63) / 64, pairs), dim3(64), 0, s, a, hp);
+            }
+            return;
+        }
         hipLaunchKernelGGL(k_exact_box_vscan, dim3((a.w + 63) / 64, pairs * 5), dim3(64), 0, s, a);
         hipLaunchKernelGGL(k_exact_box_hscan, dim3((a.h + 63) / 64, pairs * 5), dim3(64), 0, s, a);
         hipLaunchKernelGGL(k_exact_box_solve, dim3((a.w + 63) / 64, (a.h + 3) / 4, pairs), dim3(256), 0, s, a);

@@ -99,8 +99,10 @@ struct RcPolyArgs {
 // The first three change results (timing only); every other bit selects a bit-identical alternative.
 enum RcAblate : int {
     RC_ABL_STAGE_A_ONLY = 1,         // winsize-3 kernels: stop after the first matrices stage
+    RC_ABL_EXACT_PLAIN_SCANS = 2,    // option exact, box windows of winsize 3 / 5: the plain scans (V and G row-major in HBM, separate solve)
     RC_ABL_NO_WINDOW = 4,            // skip window / solve / store
     RC_ABL_EMPTY_BLOCKS = 8,         // launch cost only
+    RC_ABL_RR_DB = 32,               // register-row kernel with two R1 windows: the next tile's loads fly during the compute phase
     RC_ABL_W3X2_LDS_M = 64,          // fused pair with M in LDS (first form)
     RC_ABL_RR_28X20 = 128,           // register-row kernel: 28x20 tile, 5 blocks per CU
     RC_ABL_RR_28X12 = 256,           //   28x12 tile, 6 blocks per CU
@@ -162,6 +164,7 @@ struct RcExactArgs {
     void* G;                  // box window: [pairs][5][h][w] double running row sums
     char* out;                // last iteration of scale 0: the caller's buffer (else null -> flow)
     size_t out_step, out_pair_stride;
+    int plain_scans;          // RC_ABL_EXACT_PLAIN_SCANS
     RcWindow win;
 };
 void rc_launch_exact_polyexp(const RcPolyArgs& a, int frames, hipStream_t s);

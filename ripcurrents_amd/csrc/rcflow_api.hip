@@ -695,7 +695,9 @@ static int compute_flows_exact(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, flo
     const size_t n0 = (size_t)pl.lv[0].w * pl.lv[0].h;
     int rc;
     if ((rc = rc_buf_ensure(s.exM, n0 * 5 * pairs * sizeof(float)))) return rc;
-    if ((rc = rc_buf_ensure(s.exV, n0 * 5 * pairs * (pl.win.gaussian ? sizeof(float) : sizeof(double))))) return rc;
+    // (box windows: the column sums may be stored transposed with rows padded to a multiple of 16)
+    const size_t n0p = (size_t)pl.lv[0].w * ((pl.lv[0].h + 15) & ~15);
+    if ((rc = rc_buf_ensure(s.exV, pl.win.gaussian ? n0 * 5 * pairs * sizeof(float) : n0p * 5 * pairs * sizeof(double)))) return rc;
     if (!pl.win.gaussian && (rc = rc_buf_ensure(s.exG, n0 * 5 * pairs * sizeof(double)))) return rc;
     const float2* coarse = nullptr;
     int cw = 0, ch = 0;
@@ -705,7 +707,7 @@ static int compute_flows_exact(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, flo
         memset(&a, 0, sizeof(a));
         a.RA = (const float4*)s.RA[k].p; a.RB = (const float*)s.RB[k].p; a.n = (size_t)L.w * L.h;
         a.slot0 = slot0; a.slot1 = slot1 >= 0 ? slot1 : (slot0 + 1) % pl.nslots; a.nslots = pl.nslots; a.zstep = zstep;
-        a.w = L.w; a.h = L.h; a.win = pl.win;
+        a.w = L.w; a.h = L.h; a.win = pl.win; a.plain_scans = (ctx->ablate & RC_ABL_EXACT_PLAIN_SCANS) != 0;
         a.flow = (float2*)s.FA[k].p; a.M = (float*)s.exM.p; a.V = s.exV.p; a.G = s.exG.p;
         if (coarse) {
             a.fin = coarse; a.fin_pair_stride = (size_t)cw * ch; a.fin_w = cw; a.fin_h = ch;
@@ -1302,12 +1304,12 @@ extern "C" int rcflow_stage_flow_iter_dev(rc_ctx* ctx, int stream, const float* 
     host_window(winsize, flags, win);
     if (ctx->exact == 1) {
         if ((rc = rc_buf_ensure(s->exM, n * 5 * sizeof(float)))) return rc;
-        if ((rc = rc_buf_ensure(s->exV, n * 5 * sizeof(double)))) return rc;
+        if ((rc = rc_buf_ensure(s->exV, (size_t)w * ((h + 15) & ~15) * 5 * sizeof(double)))) return rc;
         if ((rc = rc_buf_ensure(s->exG, n * 5 * sizeof(double)))) return rc;
         if ((rc = rc_buf_ensure(s->stage_f32[2], n * sizeof(float2)))) return rc;
         RcExactArgs e;
         memset(&e, 0, sizeof(e));
-        e.RA = RA; e.RB = RB; e.n = n; e.slot0 = 0; e.slot1 = 1; e.nslots = 2; e.zstep = 1; e.w = w; e.h = h; e.win = win;
+        e.RA = RA; e.RB = RB; e.n = n; e.slot0 = 0; e.slot1 = 1; e.nslots = 2; e.zstep = 1; e.w = w; e.h = h; e.win = win; e.plain_scans = (ctx->ablate & RC_ABL_EXACT_PLAIN_SCANS) != 0;
         e.flow = (float2*)s->stage_f32[2].p; e.M = (float*)s->exM.p; e.V = s->exV.p; e.G = s->exG.p;
         if (d_flow_in) RC_HIP(hipMemcpyAsync(e.flow, d_flow_in, n * sizeof(float2), hipMemcpyDeviceToDevice, s->cur));
         else RC_HIP(hipMemsetAsync(e.flow, 0, n * sizeof(float2), s->cur));

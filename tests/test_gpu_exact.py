@@ -262,3 +262,23 @@ def test_exact_strided_buffers_and_two_slots(exact, orc):
         got = exact.calcOpticalFlowFarneback(d[0], d[1], None, stream=1, **p)
         exact.sync(1)
         assert np.array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("size", [(258, 131), (1000, 562), (130, 67), (66, 34)])
+@pytest.mark.parametrize("p", [RC215, AND167, dict(RC215, winsize=4, levels=1)])
+def test_exact_box_scans_transposed_and_plain_agree(exact, orc, size, p):
+    """Box windows of winsize 3 / 5 run the coalesced form of upstream's two sequential scans (column sums handed over
+    transposed, row scan + solve per image row); `ablate` 2 selects the plain scans.  Same bits, ragged sizes included
+    (widths that are not multiples of 64, heights that are not multiples of 16), and both equal the oracle."""
+    w, h = size
+    clip = synth.surf_clip(w, h, 3, seed=21)
+    ref = orc.farneback(clip[0], clip[1], **_o(p))
+    d = torch.as_tensor(clip).cuda()
+    a = exact.farneback_clip(d, **p).clone()
+    exact.set_option("ablate", 2)
+    try:
+        b = exact.farneback_clip(d, **p).clone()
+    finally:
+        exact.set_option("ablate", 0)
+    assert torch.equal(a, b)
+    assert np.array_equal(a[0].cpu().numpy(), ref)
