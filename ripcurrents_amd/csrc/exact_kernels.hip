@@ -231,28 +231,25 @@ __global__ __launch_bounds__(256) void k_exact_flow_init(RcExactArgs a) {
 }
 
 // ------------------------------------------------------------------ FarnebackUpdateMatrices
-__global__ __launch_bounds__(256) void k_exact_matrices(RcExactArgs a) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
-    const int width = a.w, height = a.h;
-    if (x >= width || y >= height) return;
-    const size_t s0 = (size_t)((a.slot0 + z * a.zstep) % a.nslots) * a.n;
-    const size_t s1 = (size_t)((a.slot1 + z * a.zstep) % a.nslots) * a.n;
-    const float4* RA0 = a.RA + s0; const float* RB0 = a.RB + s0;
-    const float4* RA1 = a.RA + s1; const float* RB1 = a.RB + s1;
-    const size_t p0 = (size_t)y * width + x;
-    const float2 d = a.flow[(size_t)z * a.n + p0];
-    const float dx = d.x, dy = d.y;
+// One pixel in optflow.cpp's operation order (no fused multiply-adds): the footprint's position first, then the five
+// matrix entries from the pixel's R0, the four R1 texels under the displaced position and the flow.
+struct RcExFoot { int x1, y1; float fx, fy; bool inside; };
+__device__ __forceinline__ RcExFoot rc_exact_foot(int x, int y, float dx, float dy, int width, int height) {
+    RcExFoot f;
     float fx = x + dx, fy = y + dy;
-    const int x1 = rc_cvt_i32_x86(floorf(fx)), y1 = rc_cvt_i32_x86(floorf(fy));
+    f.x1 = rc_cvt_i32_x86(floorf(fx)); f.y1 = rc_cvt_i32_x86(floorf(fy));
+    f.fx = fx - f.x1;
+    f.fy = fy - f.y1;
+    f.inside = (unsigned)f.x1 < (unsigned)(width - 1) && (unsigned)f.y1 < (unsigned)(height - 1);
+    return f;
+}
+__device__ __forceinline__ void rc_exact_m5(const RcExFoot& ft, const float4 A0, const float B0, const float4 q00,
+                                            const float4 q01, const float4 q10, const float4 q11, float e00, float e01,
+                                            float e10, float e11, float dx, float dy, int x, int y, int width,
+                                            int height, float (&M)[5]) {
     float r2, r3, r4, r5, r6;
-    fx -= x1;
-    fy -= y1;
-    const float4 A0 = RA0[p0];
-    const float B0 = RB0[p0];
-    if ((unsigned)x1 < (unsigned)(width - 1) && (unsigned)y1 < (unsigned)(height - 1)) {
-        const size_t p = (size_t)y1 * width + x1;
-        const float4 q00 = RA1[p], q01 = RA1[p + 1], q10 = RA1[p + width], q11 = RA1[p + width + 1];
-        const float e00 = RB1[p], e01 = RB1[p + 1], e10 = RB1[p + width], e11 = RB1[p + width + 1];
+    const float fx = ft.fx, fy = ft.fy;
+    if (ft.inside) {
         const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
         r2 = a00 * q00.x + a01 * q01.x + a10 * q10.x + a11 * q11.x;
         r3 = a00 * q00.y + a01 * q01.y + a10 * q10.y + a11 * q11.y;
@@ -279,12 +276,41 @@ __global__ __launch_bounds__(256) void k_exact_matrices(RcExactArgs a) {
                             (y < 5 ? (y < 2 ? b0 : b2) : 1.f) * (y >= height - 5 ? (ry < 2 ? b0 : b2) : 1.f);
         r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
     }
-    float* M = a.M + (size_t)z * 5 * a.n + p0;
     M[0] = r4 * r4 + r6 * r6;
-    M[a.n] = (r4 + r5) * r6;
-    M[2 * a.n] = r5 * r5 + r6 * r6;
-    M[3 * a.n] = r4 * r2 + r6 * r3;
-    M[4 * a.n] = r6 * r2 + r5 * r3;
+    M[1] = (r4 + r5) * r6;
+    M[2] = r5 * r5 + r6 * r6;
+    M[3] = r4 * r2 + r6 * r3;
+    M[4] = r6 * r2 + r5 * r3;
+}
+
+__global__ __launch_bounds__(256) void k_exact_matrices(RcExactArgs a) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
+    const int width = a.w, height = a.h;
+    if (x >= width || y >= height) return;
+    const size_t s0 = (size_t)((a.slot0 + z * a.zstep) % a.nslots) * a.n;
+    const size_t s1 = (size_t)((a.slot1 + z * a.zstep) % a.nslots) * a.n;
+    const float4* RA0 = a.RA + s0; const float* RB0 = a.RB + s0;
+    const float4* RA1 = a.RA + s1; const float* RB1 = a.RB + s1;
+    const size_t p0 = (size_t)y * width + x;
+    const float2 d = a.flow[(size_t)z * a.n + p0];
+    const RcExFoot ft = rc_exact_foot(x, y, d.x, d.y, width, height);
+    const float4 A0 = RA0[p0];
+    const float B0 = RB0[p0];
+    float4 q00 = A0, q01 = A0, q10 = A0, q11 = A0;
+    float e00 = B0, e01 = B0, e10 = B0, e11 = B0;
+    if (ft.inside) {
+        const size_t p = (size_t)ft.y1 * width + ft.x1;
+        q00 = RA1[p]; q01 = RA1[p + 1]; q10 = RA1[p + width]; q11 = RA1[p + width + 1];
+        e00 = RB1[p]; e01 = RB1[p + 1]; e10 = RB1[p + width]; e11 = RB1[p + width + 1];
+    }
+    float Mv[5];
+    rc_exact_m5(ft, A0, B0, q00, q01, q10, q11, e00, e01, e10, e11, d.x, d.y, x, y, width, height, Mv);
+    float* M = a.M + (size_t)z * 5 * a.n + p0;
+    M[0] = Mv[0];
+    M[a.n] = Mv[1];
+    M[2 * a.n] = Mv[2];
+    M[3 * a.n] = Mv[3];
+    M[4 * a.n] = Mv[4];
 }
 
 __device__ __forceinline__ float2 rc_exact_solve(double g11, double g12, double g22, double h1, double h2) {
@@ -436,6 +462,111 @@ __global__ __launch_bounds__(64) void k_exact_box_vscan_t(RcExactArgs a, int hp)
     }
 }
 
+// (`ablate` 16; measured slower than the two kernels it replaces: 266 vs 258 us per 1080p pair in 32-pair clips, 519 vs 357 in
+// 8-pair clips -- one wave per 64 columns and pair is too little parallelism for its chains of loads.)
+// FarnebackUpdateMatrices evaluated inside the column scan: M never goes to memory.  One lane per image column walks down
+// the rows; the matrices of the row entering the window are computed on the spot (the rows leaving it wait in a register
+// ring), four rows per pipeline stage: the stage after next loads its flow and R0 texels, the next stage has its R1
+// gathers in flight, the current one is evaluated.  Same arithmetic per pixel as k_exact_matrices + k_exact_box_vscan_t.
+template <int MM>
+__global__ __launch_bounds__(64) void k_exact_box_mvscan_t(RcExactArgs a, int hp) {
+    constexpr int m = MM, L = 2 * MM + 1, S = 4, FL = 8;
+    __shared__ double T[5][64 * (FL + 1)];
+    const int lane = threadIdx.x;
+    const int x0 = blockIdx.x * 64, x = min(x0 + lane, a.w - 1);
+    const int z = blockIdx.y;
+    const int h = a.h, w = a.w;
+    const size_t s0 = (size_t)((a.slot0 + z * a.zstep) % a.nslots) * a.n;
+    const size_t s1 = (size_t)((a.slot1 + z * a.zstep) % a.nslots) * a.n;
+    const float4* __restrict__ RA0 = a.RA + s0; const float* __restrict__ RB0 = a.RB + s0;
+    const float4* __restrict__ RA1 = a.RA + s1; const float* __restrict__ RB1 = a.RB + s1;
+    const float2* __restrict__ flow = a.flow + (size_t)z * a.n;
+    double* VT = (double*)a.V + (size_t)z * 5 * (size_t)w * hp;
+    const size_t cs = (size_t)w * hp;
+
+    struct St1 { float2 f; float4 A0; float B0; };
+    struct Ga { float4 q00, q01, q10, q11; float e00, e01, e10, e11; };
+    auto load1 = [&](int r, St1& st) {
+        const size_t p0 = (size_t)r * w + x;
+        st.f = flow[p0]; st.A0 = RA0[p0]; st.B0 = RB0[p0];
+    };
+    auto gather = [&](int r, const St1& st, Ga& g) {
+        const RcExFoot ft = rc_exact_foot(x, r, st.f.x, st.f.y, w, h);
+        // (a footprint outside the image is not used: its four loads read the pixel's own texel)
+        const size_t p = ft.inside ? (size_t)ft.y1 * w + ft.x1 : (size_t)r * w + x;
+        const size_t pw = ft.inside ? (size_t)w : 0, p1 = ft.inside ? 1 : 0;
+        g.q00 = RA1[p]; g.q01 = RA1[p + p1]; g.q10 = RA1[p + pw]; g.q11 = RA1[p + pw + p1];
+        g.e00 = RB1[p]; g.e01 = RB1[p + p1]; g.e10 = RB1[p + pw]; g.e11 = RB1[p + pw + p1];
+    };
+    auto mats = [&](int r, const St1& st, const Ga& g, float (&Mv)[5]) {
+        const RcExFoot ft = rc_exact_foot(x, r, st.f.x, st.f.y, w, h);
+        rc_exact_m5(ft, st.A0, st.B0, g.q00, g.q01, g.q10, g.q11, g.e00, g.e01, g.e10, g.e11, st.f.x, st.f.y, x, r, w, h, Mv);
+    };
+
+    // rows 0 .. m-1: upstream's initial column sums, and the ring = M of rows -m-1 .. m-1 (clamped)
+    float Mi[MM][5];
+#pragma unroll
+    for (int j = 0; j < MM; j++) {
+        St1 st; Ga g;
+        const int r = min(j, h - 1);
+        load1(r, st); gather(r, st, g); mats(r, st, g, Mi[j]);
+    }
+    double vsum[5];
+    float ring[L][5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        vsum[c] = Mi[0][c] * (m + 2);                        // float product
+#pragma unroll
+        for (int y = 1; y < m; y++) vsum[c] += Mi[y][c];
+#pragma unroll
+        for (int j = 0; j < L; j++) ring[j][c] = Mi[j - m - 1 > 0 ? j - m - 1 : 0][c];
+    }
+
+    St1 sa[S], sb[S], sc[S];
+    Ga ga[S], gb[S];
+    auto row_of = [&](int y) { return min(y + m, h - 1); };   // the row entering the window at step y
+#pragma unroll
+    for (int u = 0; u < S; u++) load1(row_of(u), sa[u]);
+#pragma unroll
+    for (int u = 0; u < S; u++) load1(row_of(S + u), sb[u]);
+#pragma unroll
+    for (int u = 0; u < S; u++) gather(row_of(u), sa[u], ga[u]);
+    for (int y0 = 0; y0 < hp; y0 += S) {
+#pragma unroll
+        for (int u = 0; u < S; u++) load1(row_of(y0 + 2 * S + u), sc[u]);
+#pragma unroll
+        for (int u = 0; u < S; u++) gather(row_of(y0 + S + u), sb[u], gb[u]);
+#pragma unroll
+        for (int u = 0; u < S; u++) {
+            float Mn[5];
+            mats(row_of(y0 + u), sa[u], ga[u], Mn);
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                vsum[c] += Mn[c] - ring[0][c];               // float difference, double sum (rows past the image: nobody reads them)
+#pragma unroll
+                for (int j = 0; j < L - 1; j++) ring[j][c] = ring[j + 1][c];
+                ring[L - 1][c] = Mn[c];
+                T[c][lane * (FL + 1) + ((y0 + u) & (FL - 1))] = vsum[c];
+            }
+        }
+        if (((y0 + S) & (FL - 1)) == 0) {
+            const int yb = y0 + S - FL;
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 5; c++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int xl = i * 16 + (lane >> 2), yy = (lane & 3) * 2;
+                    const double v0 = T[c][xl * (FL + 1) + yy], v1 = T[c][xl * (FL + 1) + yy + 1];
+                    if (x0 + xl < w) *(double2*)(VT + c * cs + (size_t)(x0 + xl) * hp + yb + yy) = make_double2(v0, v1);
+                }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < S; u++) { sa[u] = sb[u]; sb[u] = sc[u]; ga[u] = gb[u]; }
+    }
+}
+
 template <int MM>
 __global__ __launch_bounds__(64) void k_exact_box_hsolve_t(RcExactArgs a, int hp) {
     constexpr int m = MM, L = 2 * MM + 1, U = 16;
@@ -517,15 +648,30 @@ void rc_launch_exact_flow_init(const RcExactArgs& a, int pairs, hipStream_t s) {
 void rc_launch_exact_matrices(const RcExactArgs& a, int pairs, hipStream_t s) {
     hipLaunchKernelGGL(k_exact_matrices, dim3((a.w + 63) / 64, (a.h + 3) / 4, pairs), dim3(256), 0, s, a);
 }
+// Box windows of winsize 3 / 5 on 16-byte aligned flow rows: matrices + column scan in one kernel, then row scan + solve
+static bool rc_exact_box_t_ok(const RcExactArgs& a) {
+    // (the flow rows are written as float4 pairs: 16-byte aligned rows only; any other shape takes the plain scans)
+    const bool al16 = a.out ? ((((size_t)a.out) | a.out_step | a.out_pair_stride) & 15) == 0 : (a.w % 2) == 0;
+    return !a.win.gaussian && (a.win.m == 1 || a.win.m == 2) && al16 && !a.plain_scans;
+}
+int rc_exact_iteration_fused_ok(const RcExactArgs& a) { return rc_exact_box_t_ok(a) && a.fused_matrices; }
+void rc_launch_exact_iteration_fused(const RcExactArgs& a, int pairs, hipStream_t s) {
+    const int hp = (a.h + 15) & ~15;
+    if (a.win.m == 1) {
+        hipLaunchKernelGGL(k_exact_box_mvscan_t<1>, dim3((a.w + 63) / 64, pairs), dim3(64), 0, s, a, hp);
+        hipLaunchKernelGGL(k_exact_box_hsolve_t<1>, dim3((a.h + 63) / 64, pairs), dim3(64), 0, s, a, hp);
+    } else {
+        hipLaunchKernelGGL(k_exact_box_mvscan_t<2>, dim3((a.w + 63) / 64, pairs), dim3(64), 0, s, a, hp);
+        hipLaunchKernelGGL(k_exact_box_hsolve_t<2>, dim3((a.h + 63) / 64, pairs), dim3(64), 0, s, a, hp);
+    }
+}
 void rc_launch_exact_window_solve(const RcExactArgs& a, int pairs, hipStream_t s) {
     if (a.win.gaussian) {
         hipLaunchKernelGGL(k_exact_gauss_v, dim3((a.w + 63) / 64, (a.h + 3) / 4, pairs * 5), dim3(256), 0, s, a);
         hipLaunchKernelGGL(k_exact_gauss_h_solve, dim3((a.w + 63) / 64, (a.h + 3) / 4, pairs), dim3(256), 0, s, a);
     } else {
-        // (the flow rows are written as float4 pairs: 16-byte aligned rows only; any other shape takes the plain scans)
-        const bool al16 = a.out ? ((((size_t)a.out) | a.out_step | a.out_pair_stride) & 15) == 0 : (a.w % 2) == 0;
         const int hp = (a.h + 15) & ~15;
-        if ((a.win.m == 1 || a.win.m == 2) && al16 && !a.plain_scans) {
+        if (rc_exact_box_t_ok(a)) {
             if (a.win.m == 1) {
                 hipLaunchKernelGGL(k_exact_box_vscan_t<1>, dim3((a.w + 63) / 64, pairs * 5), dim3(64), 0, s, a, hp);
                 hipLaunchKernelGGL(k_exact_box_hsolve_t<1>, dim3((a.h + 63) / 64, pairs), dim3(64), 0, s, a, hp);

@@ -100,6 +100,7 @@ struct RcPolyArgs {
 enum RcAblate : int {
     RC_ABL_STAGE_A_ONLY = 1,         // winsize-3 kernels: stop after the first matrices stage
     RC_ABL_EXACT_PLAIN_SCANS = 2,    // option exact, box windows of winsize 3 / 5: the plain scans (V and G row-major in HBM, separate solve)
+    RC_ABL_EXACT_FUSED_M = 16,       // option exact, box windows of winsize 3 / 5: FarnebackUpdateMatrices inside the column scan (measured slower)
     RC_ABL_NO_WINDOW = 4,            // skip window / solve / store
     RC_ABL_EMPTY_BLOCKS = 8,         // launch cost only
     RC_ABL_RR_DB = 32,               // register-row kernel with two R1 windows: the next tile's loads fly during the compute phase
@@ -165,12 +166,16 @@ struct RcExactArgs {
     char* out;                // last iteration of scale 0: the caller's buffer (else null -> flow)
     size_t out_step, out_pair_stride;
     int plain_scans;          // RC_ABL_EXACT_PLAIN_SCANS
+    int fused_matrices;       // RC_ABL_EXACT_FUSED_M
     RcWindow win;
 };
 void rc_launch_exact_polyexp(const RcPolyArgs& a, int frames, hipStream_t s);
 void rc_launch_exact_flow_init(const RcExactArgs& a, int pairs, hipStream_t s);
 void rc_launch_exact_matrices(const RcExactArgs& a, int pairs, hipStream_t s);
 void rc_launch_exact_window_solve(const RcExactArgs& a, int pairs, hipStream_t s);
+// box windows of winsize 3 / 5: matrices + window + solve of one iteration without M in HBM (reads a.flow, writes a.flow / a.out)
+int rc_exact_iteration_fused_ok(const RcExactArgs& a);
+void rc_launch_exact_iteration_fused(const RcExactArgs& a, int pairs, hipStream_t s);
 
 // Raises a kernel's dynamic-LDS limit once per (call site, device): the attribute is per device, and a
 // process may hold contexts on several devices.

@@ -708,6 +708,7 @@ static int compute_flows_exact(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, flo
         a.RA = (const float4*)s.RA[k].p; a.RB = (const float*)s.RB[k].p; a.n = (size_t)L.w * L.h;
         a.slot0 = slot0; a.slot1 = slot1 >= 0 ? slot1 : (slot0 + 1) % pl.nslots; a.nslots = pl.nslots; a.zstep = zstep;
         a.w = L.w; a.h = L.h; a.win = pl.win; a.plain_scans = (ctx->ablate & RC_ABL_EXACT_PLAIN_SCANS) != 0;
+        a.fused_matrices = (ctx->ablate & RC_ABL_EXACT_FUSED_M) != 0;
         a.flow = (float2*)s.FA[k].p; a.M = (float*)s.exM.p; a.V = s.exV.p; a.G = s.exG.p;
         if (coarse) {
             a.fin = coarse; a.fin_pair_stride = (size_t)cw * ch; a.fin_w = cw; a.fin_h = ch;
@@ -717,12 +718,17 @@ static int compute_flows_exact(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, flo
         const double nb = (double)pairs * a.n;
         { RcProfScope ps(ctx, s.cur, RC_K_ITER, k, 8. * nb + (coarse ? 8. * pairs * cw * ch : 0.));
           rc_launch_exact_flow_init(a, pairs, s.cur); }
-        if (iters > 0) { RcProfScope ps(ctx, s.cur, RC_K_ITER, k, 68. * nb); rc_launch_exact_matrices(a, pairs, s.cur); }
         for (int i = 0; i < iters; i++) {
             if (k == 0 && i == iters - 1) { a.out = (char*)d_out; a.out_step = out_step; a.out_pair_stride = out_pair_stride; }
+            if (rc_exact_iteration_fused_ok(a)) {
+                // matrices inside the column scan: flow 8 + R0 20 + R1 20 -> V 40; V 40 -> flow 8
+                RcProfScope ps(ctx, s.cur, RC_K_ITER, k, 136. * nb);
+                rc_launch_exact_iteration_fused(a, pairs, s.cur);
+                continue;
+            }
+            { RcProfScope ps(ctx, s.cur, RC_K_ITER, k, 68. * nb); rc_launch_exact_matrices(a, pairs, s.cur); }
             { RcProfScope ps(ctx, s.cur, RC_K_ITER, k, (pl.win.gaussian ? 68. : 108.) * nb);
               rc_launch_exact_window_solve(a, pairs, s.cur); }
-            if (i < iters - 1) { RcProfScope ps(ctx, s.cur, RC_K_ITER, k, 68. * nb); rc_launch_exact_matrices(a, pairs, s.cur); }
         }
         if (k == 0 && iters == 0)
             for (int z = 0; z < pairs; z++)
