@@ -118,11 +118,14 @@ def main():
     # RC_REHEARSE_GLOO=1: rehearsal of the N>1 path on a one-GPU box (every rank on cuda:0, gloo
     # transport); never set by the driver
     rehearse = os.environ.get("RC_REHEARSE_GLOO") == "1"
+    # RC_FORCE_DIST=1: the N>1 code path (process group, collectives, barriers) with however many ranks there are --
+    # with one rank under torch.distributed.run it rehearses the RCCL backend on a one-GPU box; never set by the driver
+    multi = world > 1 or os.environ.get("RC_FORCE_DIST") == "1"
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         if rehearse:
             dist.init_process_group("gloo")
         else:
@@ -164,9 +167,9 @@ def main():
         ctx.set_option("chunk", args.chunk)
     ctx.analysis_reset(W, H)
     hist_words = ctx.histogram_words()
-    use_cabi = world > 1 and args.collective == "rccl" and not rehearse
+    use_cabi = multi and args.collective == "rccl" and not rehearse
     if use_cabi:
-        init_comm(ctx)
+        init_comm(ctx, rccl_for_one=os.environ.get("RC_FORCE_DIST") == "1")
 
     pending = []
     cabi_pending = []
@@ -259,7 +262,7 @@ def main():
                 ctx.streamline(c3_seeds, flows[t], 2.0, 1, 100.0, variant=3)
                 ctx.streamline(c3_streak, flows[t], 1.0, 1, 0.0, variant=4)
         ctx.histogram_accumulate_clip(flows)
-        if world > 1:
+        if multi:
             # global flow histogram: integer sum over RCCL, order independent; every
             # rank then derives the same global thresholds from the same integers.  The 7.5 KB
             # collective of step k runs on RCCL's stream beside the flow kernels of step k+1 and
@@ -294,7 +297,7 @@ def main():
     while args.warmup_seconds > 0:
         torch.cuda.synchronize()
         more = torch.tensor([1 if time.perf_counter() - t_w < args.warmup_seconds else 0], device=dev)
-        if world > 1:
+        if multi:
             dist.broadcast(more, 0)
         if not int(more.item()):
             break
@@ -306,7 +309,7 @@ def main():
     events = not args.no_kernel_events
     if events:
         ctx.profile_reset()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -318,11 +321,11 @@ def main():
         step()
     finish_pending()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -368,7 +371,7 @@ def main():
                                       "; + 250 seed streamlines and 5 streakline points advected through every field" if args.config == "c3" else ""),
                        "pairs_per_step": args.pairs, "segments": world,
                        "collective": ("all_reduce int32[1887] per step" + ("" if args.sync_collective else ", overlapped with the next step")
-                                      + (" (rcflow_allreduce_hist, librccl)" if use_cabi else " (torch.distributed)")) if world > 1 else "none"},
+                                      + (" (rcflow_allreduce_hist, librccl)" if use_cabi else " (torch.distributed)")) if multi else "none"},
             "warmup_steps_run": warm_run,
             "survey_model": {"bytes_per_frame": model_b,
                              "frac_of_8TBs": round(fps / world * model_b / (HBM_PEAK_GBS * 1e9), 4),
@@ -443,7 +446,7 @@ def main():
                                                     "sample": "%d pairs, row-striped std::thread (%.1f s)" % (n_mt, mt_s)}
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -321,12 +321,13 @@ int rcflow_pyrlk_levels(int w, int h, int win_w, int win_h, int max_level);
  * one process per GPU, each on its own video segment; the only exchange is the integer sum of
  * the RC_HIST_WORDS histogram counters (7548 B) over RCCL, after which every rank derives the same global
  * UPPER / UPPER2d / prop_above_upper (what ripcurrents.cpp:333-366 computes from one stream's counters).
- * librccl is opened at run time by these calls only.  A world of one rank is the identity and needs no RCCL. */
+ * librccl is opened at run time by these calls only.  A world of one rank with a NULL id is the identity and needs no
+ * RCCL; with an id it is a one-rank RCCL communicator like any other. */
 #define RC_COMM_ID_BYTES 128   /* sizeof(ncclUniqueId) */
 /* rank 0: creates the id; the host distributes it to the other ranks (MPI, a socket, a file) */
 int rcflow_comm_unique_id(void* id_out /* RC_COMM_ID_BYTES */);
 /* every rank, collectively: joins the communicator on the context's GPU.  RC_ECOMM when RCCL fails. */
-int rcflow_comm_init(rc_ctx* ctx, const void* unique_id /* RC_COMM_ID_BYTES; may be NULL when world == 1 */,
+int rcflow_comm_init(rc_ctx* ctx, const void* unique_id /* RC_COMM_ID_BYTES; NULL when world == 1: no RCCL */,
                      int rank, int world);
 int rcflow_comm_destroy(rc_ctx* ctx);
 int rcflow_comm_rank(rc_ctx* ctx, int* rank, int* world);

@@ -6,7 +6,8 @@
 //
 // librccl is opened at run time (rcflow_comm_unique_id / rcflow_comm_init), so librcflow.so itself has no
 // link-time dependency on it and single-GPU hosts never load it.  A world of one rank needs no RCCL at all:
-// the collective is then the identity.  The collective runs on its own stream: it is ordered after the slot's
+// with a null id the collective is then the identity (with an id a one-rank RCCL communicator is built like any
+// other: what the one-GPU test box can exercise of the real thing).  The collective runs on its own stream: it is ordered after the slot's
 // histogram kernels by an event, and the slot's stream only waits for it where the caller says so
 // (rcflow_allreduce_hist_join) -- the 7.5 KB all-reduce is latency-bound and hides beside the next batch.
 
@@ -91,7 +92,7 @@ extern "C" int rcflow_comm_init(rc_ctx* ctx, const void* unique_id, int rank, in
         rc_set_error("rcflow_comm_init: stream / event / buffer creation failed");
         return fail(RC_EHIP);
     }
-    if (world == 1) return RC_OK;                       // identity: no RCCL involved
+    if (world == 1 && !unique_id) return RC_OK;         // identity: no RCCL involved
     if (!(c->lib = open_rccl())) return fail(RC_ECOMM);
     auto init = (ncclResult_t(*)(ncclComm_t*, int, ncclUniqueId, int))dlsym(c->lib, "ncclCommInitRank");
     c->AllReduce = (decltype(c->AllReduce))dlsym(c->lib, "ncclAllReduce");
@@ -137,7 +138,7 @@ extern "C" int rcflow_allreduce_hist(rc_ctx* ctx, int stream, int32_t* d_words_o
     RC_HIP(hipMemcpyAsync(c->staging, s->an.hist.p, RC_HIST_WORDS * sizeof(int32_t), hipMemcpyDeviceToDevice, s->cur));
     RC_HIP(hipEventRecord(c->ready, s->cur));
     RC_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
-    if (c->world == 1) {
+    if (!c->comm) {                                     // world of one without RCCL
         RC_HIP(hipMemcpyAsync(out, c->staging, RC_HIST_WORDS * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
     } else {
         ncclResult_t r = c->AllReduce(c->staging, out, RC_HIST_WORDS, ncclInt32, ncclSum, c->comm, c->stream);

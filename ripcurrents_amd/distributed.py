@@ -13,10 +13,20 @@ used by the CPU tests), and the library's own C-ABI collective (rcflow_comm_init
 librccl opened directly) -- what a C++ host like the reference's uses; init_comm() below sets it up for a
 Python host, with torch.distributed only as the out-of-band channel that carries the 128-byte RCCL id.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from ._lib import HIST_BINS, HIST_DIRECTIONS, HIST_WORDS
+
+
+def _collective_wanted(group):
+    """An initialised group of more than one rank -- or of one rank under RC_FORCE_DIST=1, the rehearsal of the N-rank
+    code path (backend included) on a one-GPU box."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("RC_FORCE_DIST") == "1"
 
 
 def allreduce_hist_words(words, group=None):
@@ -25,7 +35,7 @@ def allreduce_hist_words(words, group=None):
     if words.numel() != HIST_WORDS or words.dtype != torch.int32:
         raise ValueError("expected %d int32 histogram words" % HIST_WORDS)
     g = words.clone()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collective_wanted(group):
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
     return g
 
@@ -53,16 +63,17 @@ def allreduce_hist_words_async(words, group=None):
         raise ValueError("expected %d int32 histogram words" % HIST_WORDS)
     g = words.clone()
     work = None
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collective_wanted(group):
         work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True)
     return PendingHistSum(work, g)
 
 
-def init_comm(ctx, group=None):
+def init_comm(ctx, group=None, rccl_for_one=False):
     """Joins the context's C-ABI communicator with the ranks of the torch.distributed group: rank 0
     creates the RCCL unique id, torch.distributed broadcasts its 128 bytes (any backend), every rank calls
-    rcflow_comm_init.  Without an initialised process group the world is one rank (identity collective)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    rcflow_comm_init.  Without an initialised process group the world is one rank (identity collective);
+    `rccl_for_one` builds a one-rank RCCL communicator for an initialised group of one instead (rehearsal)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not rccl_for_one):
         ctx.comm_init(0, 1)
         return 0, 1
     rank, world = dist.get_rank(group), dist.get_world_size(group)

@@ -61,3 +61,24 @@ def test_bench_two_ranks_rehearsal():
     assert "all_reduce int32[1887]" in j["config"]["collective"]
     assert abs(j["value"] - 2 * 4 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 0.01
     assert "cpu_baseline" not in j          # rank 0 at N = 1 only
+
+
+@pytest.mark.parametrize("collective", ["torch", "rccl"])
+def test_bench_rccl_backend_rehearsal_with_one_rank(collective):
+    """The N>1 code path of bench.py over the REAL backend, as far as one GPU allows: one rank under
+    torch.distributed.run with RC_FORCE_DIST=1 initialises the `nccl` (= RCCL) process group and runs every collective of
+    the multi-rank run -- the asynchronous int32[1887] histogram all-reduce consumed one step later (torch.distributed, or
+    the library's own rcflow_allreduce_hist over a one-rank RCCL communicator whose id travels by broadcast), the
+    warm-up broadcast, the barriers and the max-over-ranks reduction of the timing."""
+    env = dict(os.environ, RC_FORCE_DIST="1")
+    port = 29900 + os.getpid() % 90 + (0 if collective == "torch" else 1)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--pairs", "8", "--no-roof", "--no-cpu-baseline", "--warmup-seconds", "0.2", "--collective", collective]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["value"] > 1000
+    assert ("librccl" if collective == "rccl" else "torch.distributed") in j["config"]["collective"]

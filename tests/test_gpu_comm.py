@@ -51,6 +51,28 @@ def test_world_of_one_is_the_identity_and_feeds_the_thresholds(ctx, orc):
     ctx.comm_destroy()
 
 
+def test_one_rank_rccl_communicator_runs_the_real_collective(ctx):
+    """With an id, a world of one is an ordinary RCCL communicator: librccl opened at run time, ncclCommInitRank,
+    ncclAllReduce(int32[1887], sum) on the collective's own stream ordered by events, ncclCommDestroy -- every call the
+    N-rank path makes, on the one GPU this box has.  (The sum over one rank is the rank's own counters.)"""
+    w, h = 320, 240
+    rng = np.random.RandomState(5)
+    flow = (rng.randn(h, w, 2) * 0.8).astype(np.float32)
+    ctx.analysis_reset(w, h)
+    ctx.comm_init(0, 1, ctx.comm_unique_id())
+    try:
+        for rep in (1, 2, 3):
+            ctx.histogram_accumulate(flow)
+            g = ctx.allreduce_hist()
+            ctx.allreduce_hist_join()
+            ctx.sync()
+            mine = ctx.histogram_words().cpu().numpy()
+            assert np.array_equal(g.cpu().numpy(), mine)
+            assert 0 < mine[50 + 36 * 50] <= rep * w * h          # histsum: the pixels inside the 50 magnitude bins
+    finally:
+        ctx.comm_destroy()
+
+
 def test_unique_id_comes_from_librccl(ctx):
     a, b = ctx.comm_unique_id(), ctx.comm_unique_id()
     assert len(a) == 128 and a != b
