@@ -444,6 +444,30 @@ def main():
                 out["cpu_baseline"]["all_cores"] = {"value": round(n_mt / mt_s, 4), "unit": "frames/s",
                                                     "cores": ncores,
                                                     "sample": "%d pairs, row-striped std::thread (%.1f s)" % (n_mt, mt_s)}
+            # Opportunistic: a LOCALLY installed OpenCV -- never fetched -- is the real reference
+            # implementation of this path; when one exists it is timed beside the port (absent from this pool's images)
+            try:
+                import cv2
+            except Exception:
+                cv2 = None
+            if cv2 is not None:
+                def cv_run(n):
+                    t0 = time.perf_counter()
+                    for t in range(n):
+                        cv2.calcOpticalFlowFarneback(host[t % args.cpu_pairs], host[t % args.cpu_pairs + 1], None, params["pyr_scale"],
+                                                     params["levels"], params["winsize"], params["iterations"], params["poly_n"],
+                                                     params["poly_sigma"], params["flags"])
+                    return time.perf_counter() - t0
+                cv2.ocl.setUseOpenCL(False)
+                cv2.setNumThreads(1)
+                cv_run(1)
+                one = cv_run(args.cpu_pairs)
+                cv2.setNumThreads(-1)
+                cv_run(1)
+                many = cv_run(3 * args.cpu_pairs)
+                out["cpu_baseline"]["opencv"] = {"version": cv2.__version__, "kind": "reference",
+                                                 "single_thread": round(args.cpu_pairs / one, 4),
+                                                 "default_threads": round(3 * args.cpu_pairs / many, 4), "unit": "frames/s"}
         print(json.dumps(out))
     ctx.close()
     if multi:

@@ -21,6 +21,10 @@ __global__ void k(float* out, float seed) {
             if (OP == 5) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(f[i]) : "v"(f[(i + 1) % CH]), "v"(f[(i + 2) % CH]));
             if (OP == 6) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f[i]) : "v"(f[i]), "v"(f[(i + 1) % CH]));
             if (OP == 7) asm volatile("v_lshlrev_b32 %0, 3, %1\n\tv_add_u32 %0, %0, %1" : "=&v"(f[i]) : "v"(f[(i + 1) % CH]));
+            if (OP == 8) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(d[i]) : "v"(d[(i + 1) % CH]), "v"(d[(i + 2) % CH]));
+            if (OP == 9) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d[i]) : "v"(d[i]), "v"(d[(i + 1) % CH]));
+            if (OP == 10) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d[i]) : "v"(d[i]), "v"(d[(i + 1) % CH]));
+            if (OP == 11) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(f[i]) : "v"(f[i]), "v"(f[(i + 1) % CH]));
         }
     }
     float acc = 0;
@@ -49,5 +53,6 @@ int run(const char* name, int per_iter) {
 int main() {
     run<0>("v_cvt_f64_f32", 1); run<1>("v_mul_f64", 1); run<2>("v_add_f64", 1); run<3>("v_fma_f64", 1);
     run<4>("v_cvt_f32_f64", 1); run<5>("v_fma_f32", 1); run<6>("v_add_f32", 1); run<7>("2 x int op", 2);
+    run<8>("v_pk_fma_f32", 1); run<9>("v_pk_mul_f32", 1); run<10>("v_pk_add_f32", 1); run<11>("v_mul_f32", 1);
     return 0;
 }
