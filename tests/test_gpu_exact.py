@@ -285,3 +285,22 @@ def test_exact_box_scans_transposed_and_plain_agree(exact, orc, size, p):
     assert torch.equal(a, b)
     assert torch.equal(a, c)
     assert np.array_equal(a[0].cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_exact_randomised_shapes_and_parameters(exact, orc, seed):
+    """Sixteen seeded draws over image size (33 .. 420, even and odd, wider than tall and the reverse), pyramid scale and
+    depth, window size and kind, iteration count and expansion size -- the generic kernels as well as the instantiated
+    ones, cropped pyramids, both 16-byte-aligned and unaligned rows for the box-window scans: the oracle's bits every time."""
+    rng = np.random.RandomState(7000 + seed)
+    w, h = int(rng.randint(33, 421)), int(rng.randint(33, 421))
+    p = dict(pyr_scale=float(rng.choice([0.5, 0.5, 0.6, 0.75, 0.8])), levels=int(rng.randint(0, 5)),
+             winsize=int(rng.choice([1, 2, 3, 3, 4, 5, 5, 7, 10, 13, 20])), iterations=int(rng.randint(1, 4)),
+             poly_n=int(rng.choice([5, 7, 15])), poly_sigma=float(rng.choice([1.1, 1.2, 1.5])),
+             flags=int(rng.choice([0, 256])))
+    clip = synth.surf_clip(w, h, 3, seed=int(rng.randint(1 << 30)))
+    d = torch.as_tensor(clip).cuda()
+    got = exact.farneback_clip(d, **p).cpu().numpy()
+    for t in range(2):
+        ref = orc.farneback(clip[t], clip[t + 1], nthreads=4, **_o(p))
+        assert np.array_equal(got[t], ref), (w, h, p, t, float(np.abs(got[t] - ref).max()))

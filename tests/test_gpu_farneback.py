@@ -454,6 +454,23 @@ def test_parameter_sweep_beyond_the_reference_call_sites(ctx, orc, i):
     assert st["p50"] <= 2e-4
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_shapes_and_parameters_default_options(ctx, orc, seed):
+    """Twelve seeded draws over size (120 .. 420, even and odd), pyramid ratio and depth, window, iterations and expansion
+    size through the DEFAULT options (fast kernels; the exact path where `exact` = -1 selects it), against the oracle with
+    SURVEY 8(d)'s conditioned metric."""
+    rng = np.random.RandomState(9000 + seed)
+    w, h = int(rng.randint(120, 421)), int(rng.randint(120, 421))
+    p = dict(pyr_scale=float(rng.choice([0.5, 0.5, 0.6, 0.75, 0.8])), levels=int(rng.randint(0, 4)),
+             winsize=int(rng.choice([3, 3, 4, 5, 5, 7, 10, 13, 20])), iterations=int(rng.randint(1, 4)),
+             poly_n=int(rng.choice([5, 7, 15])), poly_sigma=float(rng.choice([1.1, 1.2, 1.5])),
+             flags=int(rng.choice([0, 256])))
+    clip = synth.surf_clip(w, h, 2, seed=int(rng.randint(1 << 30)))
+    ref, det_last = _oracle_diag(orc, clip[0], clip[1], p)
+    got = ctx.calcOpticalFlowFarneback(clip[0], clip[1], None, **p)
+    assert_conditioned("random %d: %dx%d %s" % (seed, w, h, p), got, ref, *det_last, tier="config" if min(w, h) >= 200 else "stress")
+
+
 def _hostile_images(w, h):
     rng = np.random.RandomState(1)
     yy, xx = np.mgrid[0:h, 0:w]
