@@ -36,7 +36,7 @@
 #define RC_DB_ABL 0       // timing-only cuts of k_flow_iter2_db: 1 = no global loads, 2 = the loads alone, 3 = no wait for the prefetch
 #endif
 #ifndef RC_RR_PRIO
-#define RC_RR_PRIO 0      // k_flow_iter2_rr experiment: wave priority per block (1: blockIdx & 3, 2: (blockIdx >> 3) & 3, 3: HW thread-group slot & 3)
+#define RC_RR_PRIO 0      // k_flow_iter2_rr experiment: wave priority per block (1: blockIdx & 3, 2: (blockIdx >> 3) & 3, 3: HW thread-group slot & 3), per phase (4: loads high, 5: compute high)
 #endif
 #ifndef RC_RR_WPAD
 #define RC_RR_WPAD 0      // extra texels per LDS row of the register-row kernel's R1 window (see k_flow_iter2_rr)
@@ -1234,7 +1234,9 @@ __global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
 #pragma unroll
     for (int q = 0; q < NIT; q++) gys[q] = rc_clampi(ty0 - 2 + ly0 + q, 0, h - 1);
     const bool interior = tx0 - 2 >= 5 && tx0 - 2 + MW <= w - 5 && ty0 - 2 >= 5 && ty0 - 2 + MH <= h - 5;
-#if RC_RR_PRIO
+#if RC_RR_PRIO == 4 || RC_RR_PRIO == 5
+    __builtin_amdgcn_s_setprio(RC_RR_PRIO == 4 ? 3 : 0);      // 4: the load phase at top priority; 5: the compute phase instead
+#elif RC_RR_PRIO
     {
 #if RC_RR_PRIO == 1
         const int pr = blockIdx.x & 3;
@@ -1374,6 +1376,9 @@ __global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
         }
     }
     __syncthreads();      // (drains the LDS-DMA)
+#if RC_RR_PRIO == 4 || RC_RR_PRIO == 5
+    __builtin_amdgcn_s_setprio(RC_RR_PRIO == 4 ? 0 : 3);
+#endif
 #if RC_RR_ABL == 1
     if (a.w > 0) {        // timing-only build: the loads alone
         float acc = LB[tid] + dx[0] + dy[NIT - 1];
