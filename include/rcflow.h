@@ -135,6 +135,13 @@ int rcflow_push_frame_dev(rc_ctx* ctx, int stream, const uint8_t* d_frame, size_
  * stream.  Interoperates with rcflow_push_frame_dev / rcflow_push_clip_dev on the same slot. */
 int rcflow_push_frame_u8(rc_ctx* ctx, int stream, const uint8_t* frame, size_t step, int w, int h,
                          const rc_farneback_params* p);
+/* Without the copy: rcflow_frame_buffer_acquire hands out the next of the slot's two page-locked staging buffers (w x h
+ * bytes, dense rows; it waits until the upload that last read that buffer has left it) for the host to produce the frame
+ * INTO -- e.g. as the destination Mat of the cvtColor at ripcurrents.cpp:210 -- and rcflow_push_frame_acquired pushes it
+ * like rcflow_push_frame_u8 does (same return values, asynchronous).  One buffer is out at a time: acquiring again, or a
+ * rcflow_push_frame_u8 on the slot, takes the same buffer back (RC_ESTATE from a push without an acquisition). */
+int rcflow_frame_buffer_acquire(rc_ctx* ctx, int stream, int w, int h, uint8_t** host_frame, size_t* step);
+int rcflow_push_frame_acquired(rc_ctx* ctx, int stream, const rc_farneback_params* p);
 int rcflow_stream_flow_ptr(rc_ctx* ctx, int stream, float** d_flow_xy, int* w, int* h);
 int rcflow_stream_flow_read(rc_ctx* ctx, int stream, float* flow_xy, size_t flow_step);
 /* Batched form of the same stream: the nframes frames continue the slot's stream, every frame is expanded

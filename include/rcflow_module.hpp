@@ -108,6 +108,30 @@ class Pipeline {
         return true;
     }
 
+    // The same loop without the staging copy: frameBuffer() is the slot's next page-locked staging buffer as an 8UC1
+    // view of the pipeline's size -- make it the destination of the cvtColor at ripcurrents.cpp:210 -- and pushAcquired()
+    // pushes it (rcflow_frame_buffer_acquire / rcflow_push_frame_acquired).
+    Mat frameBuffer() {
+        uint8_t* p = nullptr;
+        size_t step = 0;
+        check(rcflow_frame_buffer_acquire(ctx_, 0, w_, h_, &p, &step));
+        return Mat(h_, w_, 1, 1, p, step);
+    }
+    bool pushAcquired(Mat& flow, double pyr_scale, int levels, int winsize, int iterations, int poly_n, double poly_sigma,
+                      int flags) {
+        if (flow.data && (flow.rows != h_ || flow.cols != w_ || flow.channels != 2 || flow.elem != 4))
+            throw Error(RC_EINVAL, "flow must be CV_32FC2 of the frame size");
+        rc_farneback_params p = {pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags};
+        const int rc = rcflow_push_frame_acquired(ctx_, 0, &p);
+        check(rc);
+        if (rc == 1) return false;
+        float* d = nullptr;
+        check(rcflow_stream_flow_ptr(ctx_, 0, &d, nullptr, nullptr));
+        flow_src_ = d;
+        if (flow.data) check(rcflow_stream_flow_read(ctx_, 0, (float*)flow.data, flow.step));
+        return true;
+    }
+
     void calcOpticalFlowFarneback(const Mat& prev, const Mat& next, Mat& flow, double pyr_scale, int levels,
                                   int winsize, int iterations, int poly_n, double poly_sigma, int flags) {
         if (prev.empty() || next.empty() || prev.rows != next.rows || prev.cols != next.cols ||

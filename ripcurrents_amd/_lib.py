@@ -50,6 +50,8 @@ SIGNATURES = {
     "rcflow_push_frame_dev": [_vp, _i, _vp, _sz, _i, _i, _vp, _sz, _pp],
     "rcflow_stream_reset": [_vp, _i],
     "rcflow_push_frame_u8": [_vp, _i, _vp, _sz, _i, _i, _pp],
+    "rcflow_frame_buffer_acquire": [_vp, _i, _i, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
+    "rcflow_push_frame_acquired": [_vp, _i, _pp],
     "rcflow_stream_flow_ptr": [_vp, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i)],
     "rcflow_stream_flow_read": [_vp, _i, _vp, _sz],
     "rcflow_farneback_clip_dev": [_vp, _i, _vp, _sz, _sz, _i, _i, _i, _vp, _sz, _sz, _pp],

@@ -187,6 +187,26 @@ class Context:
         check(self._lib.rcflow_stream_flow_ptr(self._h, stream, C.byref(d), None, None))
         return _alias_tensor(d.value, h * w * 2, torch.float32, self.device).view(h, w, 2)
 
+    def frame_buffer(self, w, h, stream=0):
+        """The next page-locked staging buffer of the slot as a numpy HxW uint8 view (rcflow_frame_buffer_acquire): produce
+        the frame into it, then push_frame_acquired() -- the frame loop without the staging copy."""
+        ptr, step = C.c_void_p(), C.c_size_t()
+        check(self._lib.rcflow_frame_buffer_acquire(self._h, stream, w, h, C.byref(ptr), C.byref(step)))
+        buf = (C.c_uint8 * (h * step.value)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(h, step.value)[:, :w]
+
+    def push_frame_acquired(self, w, h, stream=0, **kw):
+        p = _params(kw.get("pyr_scale", 0.5), kw.get("levels", 2), kw.get("winsize", 3),
+                    kw.get("iterations", 2), kw.get("poly_n", 15), kw.get("poly_sigma", 1.2),
+                    kw.get("flags", 0))
+        self._bind(stream)
+        rc = check(self._lib.rcflow_push_frame_acquired(self._h, stream, C.byref(p)))
+        if rc == 1:
+            return None
+        d = C.c_void_p()
+        check(self._lib.rcflow_stream_flow_ptr(self._h, stream, C.byref(d), None, None))
+        return _alias_tensor(d.value, h * w * 2, torch.float32, self.device).view(h, w, 2)
+
     def stream_flow_read(self, w, h, stream=0):
         out = np.empty((h, w, 2), np.float32)
         self._bind(stream)

@@ -65,6 +65,7 @@ struct RcSlot {
     size_t pin_bytes = 0;
     hipEvent_t pin_free[2] = {nullptr, nullptr};
     int pin_i = 0;
+    int pin_acq = -1, pin_w = 0, pin_h = 0;   // staging buffer handed to the host by rcflow_frame_buffer_acquire, not yet pushed
     int flow_w = 0, flow_h = 0;   // size of the flow field resident in stage_flow (0: none yet)
     RcBuf lk;                  // sparse PyrLK pyramids + derivatives (lk_kernels.hip)
     RcBuf area_tab;            // INTER_AREA decimation tables

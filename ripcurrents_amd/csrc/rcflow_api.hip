@@ -962,14 +962,13 @@ extern "C" int rcflow_push_frame_dev(rc_ctx* ctx, int stream, const uint8_t* d_f
 // (rcflow_stream_flow_ptr) and only crosses PCIe when the host asks for it (rcflow_stream_flow_read).  The call
 // returns once the frame is in the staging buffer -- the upload of frame t and the kernels of frame t run
 // while the host decodes frame t + 1.  Returns 1 when the call only primed the stream (no flow yet).
-extern "C" int rcflow_push_frame_u8(rc_ctx* ctx, int stream, const uint8_t* frame, size_t step, int w, int h,
-                                    const rc_farneback_params* p) {
-    RcSlot* s = rc_slot(ctx, stream);
-    if (!s || !frame || w <= 0 || h <= 0 || step < (size_t)w) { if (s) rc_set_error("bad frame arguments"); return RC_EINVAL; }
+// The slot's two page-locked staging buffers for frames of w x h bytes; returns the one the next push uses, once the
+// upload that last read it has left it.
+static int frame_staging_next(rc_ctx* ctx, RcSlot* s, int w, int h, int* idx) {
+    if (w <= 0 || h <= 0) { rc_set_error("bad frame arguments"); return RC_EINVAL; }
     if (w > ctx->max_w || h > ctx->max_h) { rc_set_error("frame %dx%d exceeds the context's %dx%d", w, h, ctx->max_w, ctx->max_h); return RC_ESIZE; }
     RC_HIP(hipSetDevice(ctx->device));
     const size_t fb = (size_t)w * h;
-    int rc;
     if (s->pin_bytes < fb) {
         RC_HIP(hipStreamSynchronize(s->cur));
         for (int i = 0; i < 2; i++) {
@@ -981,21 +980,58 @@ extern "C" int rcflow_push_frame_u8(rc_ctx* ctx, int stream, const uint8_t* fram
         }
         s->pin_bytes = fb;
     }
+    int rc;
     if ((rc = rc_buf_ensure(s->stage_u8, 2 * fb))) return rc;
     if ((rc = rc_buf_ensure(s->stage_flow, fb * 8))) return rc;
-    const int i = s->pin_i;
-    RC_HIP(hipEventSynchronize(s->pin_free[i]));              // the upload that last used this staging buffer has left it
-    uint8_t* dst = (uint8_t*)s->pin[i];
-    if (step == (size_t)w) memcpy(dst, frame, fb);
-    else for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * w, frame + (size_t)y * step, w);
+    RC_HIP(hipEventSynchronize(s->pin_free[s->pin_i]));       // the upload that last used this staging buffer has left it
+    *idx = s->pin_i;
+    return RC_OK;
+}
+
+// Upload of staging buffer i (dense w x h bytes) + one step of the frame loop
+static int push_staged_frame(rc_ctx* ctx, RcSlot* s, int stream, int i, int w, int h, const rc_farneback_params* p) {
+    const size_t fb = (size_t)w * h;
     uint8_t* d_frame = (uint8_t*)s->stage_u8.p + (size_t)i * fb;
     s->pin_i = i ^ 1;
+    s->pin_acq = -1;
     // the upload belongs to the expansion's side of the two-stream frame loop (option "frame_overlap" >= 1)
-    RcFrameAux up = {dst, d_frame, fb, s->pin_free[i]};
-    rc = push_frame_core(ctx, s, stream, d_frame, w, w, h, (float*)s->stage_flow.p, (size_t)w * 8, p, ctx->frame_overlap >= 1, &up);
+    RcFrameAux up = {s->pin[i], d_frame, fb, s->pin_free[i]};
+    const int rc = push_frame_core(ctx, s, stream, d_frame, w, w, h, (float*)s->stage_flow.p, (size_t)w * 8, p, ctx->frame_overlap >= 1, &up);
     if (rc == RC_OK) { s->flow_w = w; s->flow_h = h; }
     else if (rc == 1) { s->flow_w = s->flow_h = 0; }
     return rc;
+}
+
+extern "C" int rcflow_push_frame_u8(rc_ctx* ctx, int stream, const uint8_t* frame, size_t step, int w, int h,
+                                    const rc_farneback_params* p) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !frame || w <= 0 || h <= 0 || step < (size_t)w) { if (s) rc_set_error("bad frame arguments"); return RC_EINVAL; }
+    int i, rc;
+    if ((rc = frame_staging_next(ctx, s, w, h, &i))) return rc;
+    uint8_t* dst = (uint8_t*)s->pin[i];
+    if (step == (size_t)w) memcpy(dst, frame, (size_t)w * h);
+    else for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * w, frame + (size_t)y * step, w);
+    return push_staged_frame(ctx, s, stream, i, w, h, p);
+}
+
+// The same loop without the copy: the host produces the frame INTO the staging buffer (e.g. as the destination of the
+// cvtColor at ripcurrents.cpp:210) and then pushes it.
+extern "C" int rcflow_frame_buffer_acquire(rc_ctx* ctx, int stream, int w, int h, uint8_t** host_frame, size_t* step) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !host_frame) { if (s) rc_set_error("bad frame arguments"); return RC_EINVAL; }
+    int i, rc;
+    if ((rc = frame_staging_next(ctx, s, w, h, &i))) return rc;
+    s->pin_acq = i; s->pin_w = w; s->pin_h = h;
+    *host_frame = (uint8_t*)s->pin[i];
+    if (step) *step = (size_t)w;
+    return RC_OK;
+}
+extern "C" int rcflow_push_frame_acquired(rc_ctx* ctx, int stream, const rc_farneback_params* p) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s) return RC_EINVAL;
+    if (s->pin_acq < 0 || s->pin_acq != s->pin_i) { rc_set_error("no frame buffer acquired (rcflow_frame_buffer_acquire) since the last push"); return RC_ESTATE; }
+    RC_HIP(hipSetDevice(ctx->device));
+    return push_staged_frame(ctx, s, stream, s->pin_acq, s->pin_w, s->pin_h, p);
 }
 
 // Device address of the flow field the last rcflow_push_frame_u8 produced (w x h float2, dense rows), for the

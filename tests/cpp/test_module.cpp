@@ -130,6 +130,18 @@ int main() {
         pipe.calcOpticalFlowFarneback(mb, mc, mref, 0.5, 2, 3, 2, 15, 1.2, 0);
         REQUIRE(memcmp(fl.data(), ref.data(), fl.size() * sizeof(float)) == 0);
         REQUIRE(!pipe.pushFrame(ma, mfl, 0.5, 2, 10, 3, 15, 1.2, 256));      // other parameters: primes again
+        // the same loop without the staging copy: the frame is produced into the slot's page-locked buffer
+        REQUIRE(rcflow_stream_reset(pipe.context(), 0) == 0);
+        const std::vector<uint8_t>* src[3] = {&a, &b, &c};
+        for (int t = 0; t < 3; t++) {
+            rc::Mat buf = pipe.frameBuffer();
+            REQUIRE(buf.rows == YDIM && buf.cols == XDIM && buf.step >= (size_t)XDIM);
+            for (int y = 0; y < YDIM; y++) memcpy((uint8_t*)buf.data + (size_t)y * buf.step, src[t]->data() + (size_t)y * XDIM, XDIM);
+            REQUIRE(pipe.pushAcquired(mfl, 0.5, 2, 3, 2, 15, 1.2, 0) == (t > 0));
+        }
+        REQUIRE(memcmp(fl.data(), ref.data(), fl.size() * sizeof(float)) == 0);
+        rc_farneback_params prm = {0.5, 2, 3, 2, 15, 1.2, 0};
+        REQUIRE(rcflow_push_frame_acquired(pipe.context(), 0, &prm) == RC_ESTATE);       // nothing acquired
     }
 
     // the asynchronous host loop: frames from host memory through the page-locked double buffer, the flow field

@@ -667,6 +667,42 @@ def test_host_frame_loop_pinned_double_buffer(ctx):
     ctx.stream_reset()
 
 
+def test_host_frame_loop_without_the_staging_copy(ctx):
+    """rcflow_frame_buffer_acquire / rcflow_push_frame_acquired: the host produces every frame INTO the slot's page-locked
+    staging buffer (the destination of the cvtColor at ripcurrents.cpp:210) and pushes it -- same flow fields as the
+    device-pointer loop, the two entry points mix on one slot, and a push without an acquisition is refused."""
+    from ripcurrents_amd import RcflowError
+    w, h, T = 322, 241, 8
+    clip = synth.surf_clip(w, h, T, seed=13)
+    p = dict(pyr_scale=0.5, levels=2, winsize=3, iterations=2, poly_n=15, poly_sigma=1.2, flags=0)
+    ref = ctx.farneback_clip(torch.as_tensor(clip).cuda(), **p).cpu().numpy()
+    ctx.stream_reset()
+    with pytest.raises(RcflowError) as e:
+        ctx.push_frame_acquired(w, h, **p)
+    assert e.value.code == -6          # RC_ESTATE
+    seen = set()
+    for t in range(T):
+        if t in (3, 6):                                  # the copying entry point in between
+            f = ctx.push_frame_host(clip[t], **p)
+        else:
+            buf = ctx.frame_buffer(w, h)
+            seen.add(buf.ctypes.data)
+            buf[:] = clip[t]                             # "the decoder's" write
+            f = ctx.push_frame_acquired(w, h, **p)
+        if t == 0:
+            assert f is None
+        else:
+            ctx.sync()
+            assert np.array_equal(f.cpu().numpy(), ref[t - 1]), t
+    assert len(seen) == 2                                # the two staging buffers alternate
+    # an acquisition is cancelled by a copying push on the slot
+    ctx.frame_buffer(w, h)
+    ctx.push_frame_host(clip[0], **p)
+    with pytest.raises(RcflowError):
+        ctx.push_frame_acquired(w, h, **p)
+    ctx.stream_reset()
+
+
 def test_profile_buckets_carry_the_reference_names(ctx):
     """rcflow_profile_read_buckets: GPU time under the names of ripcurrents.cpp:103-109 / :518-524."""
     w, h = 320, 240
