@@ -92,9 +92,12 @@ __global__ __launch_bounds__(256) void k_exact_polyexp(RcPolyArgs a) {
 #ifndef RC_EXP_WAVES
 #define RC_EXP_WAVES 2
 #endif
-template <int N>
+// TH rows per block: 32, or 8 for launches of a few dozen tiles (a launch of fewer blocks than the GPU holds lasts one
+// block's lifetime; the vertical pass's register window spans R + 2 N rows whatever TH is).  Same bits.
+template <int N, int TH = 32>
 __global__ __launch_bounds__(256, RC_EXP_WAVES) void k_exact_polyexp_t(RcPolyArgs a) {
-    constexpr int TW = 64, TH = 32, NP = (N + 3) & ~3, CW = TW + 2 * NP, R = 8, NW = R + 2 * N;
+    constexpr int TW = 64, NP = (N + 3) & ~3, CW = TW + 2 * NP, R = 8, NW = R + 2 * N;
+    static_assert(TH % R == 0, "whole groups of R rows");
     constexpr int PX = 2, HW = PX + 2 * NP;                // PX pixels per item; floats under their taps (8-byte aligned reads)
     __shared__ __align__(16) float rows[3][TH][CW];
     const int tid = threadIdx.x, z = blockIdx.z;
@@ -189,11 +192,19 @@ __global__ __launch_bounds__(256, RC_EXP_WAVES) void k_exact_polyexp_t(RcPolyArg
     }
 }
 
+template <int N>
+static void launch_exact_polyexp_t(const RcPolyArgs& a, int frames, hipStream_t s) {
+    const long long tiles32 = (long long)((a.w + 63) / 64) * ((a.h + 31) / 32) * frames;
+    // measured in the frame-at-a-time loop at 1080p (main.cpp:264's parameters, one frame per launch): 8-row tiles take the
+    // 480 x 270 scale from 16.8 to 11.2 us, leave 960 x 540 at 18.2 and would slow 1920 x 1080 from 42 to 47
+    if (tiles32 >= 200) hipLaunchKernelGGL((k_exact_polyexp_t<N, 32>), dim3((a.w + 63) / 64, (a.h + 31) / 32, frames), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_exact_polyexp_t<N, 8>), dim3((a.w + 63) / 64, (a.h + 7) / 8, frames), dim3(256), 0, s, a);
+}
+
 void rc_launch_exact_polyexp(const RcPolyArgs& a, int frames, hipStream_t s) {
-    dim3 tgrid((a.w + 63) / 64, (a.h + 31) / 32, frames);
-    if (a.pk.n == 15 && !a.no_fast_u8) { hipLaunchKernelGGL(k_exact_polyexp_t<15>, tgrid, dim3(256), 0, s, a); return; }
-    if (a.pk.n == 7 && !a.no_fast_u8) { hipLaunchKernelGGL(k_exact_polyexp_t<7>, tgrid, dim3(256), 0, s, a); return; }
-    if (a.pk.n == 5 && !a.no_fast_u8) { hipLaunchKernelGGL(k_exact_polyexp_t<5>, tgrid, dim3(256), 0, s, a); return; }
+    if (a.pk.n == 15 && !a.no_fast_u8) { launch_exact_polyexp_t<15>(a, frames, s); return; }
+    if (a.pk.n == 7 && !a.no_fast_u8) { launch_exact_polyexp_t<7>(a, frames, s); return; }
+    if (a.pk.n == 5 && !a.no_fast_u8) { launch_exact_polyexp_t<5>(a, frames, s); return; }
     const size_t lds = sizeof(float) * 3 * RC_EX_TH * (RC_EX_TW + 2 * a.pk.n);
     dim3 grid((a.w + RC_EX_TW - 1) / RC_EX_TW, (a.h + RC_EX_TH - 1) / RC_EX_TH, frames);
     hipLaunchKernelGGL(k_exact_polyexp, grid, dim3(256), lds, s, a);
