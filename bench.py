@@ -78,6 +78,8 @@ def main():
                          "caches at steady state however small --warmup is); 0 disables")
     ap.add_argument("--pairs", type=int, default=32, help="frame pairs (flow fields) per step")
     ap.add_argument("--chunk", type=int, default=0, help="pairs per launch (0 = library default)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="library option for same-box A/B runs (rcflow_set_option), e.g. --opt chain=1")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--event-every", type=int, default=10,
                     help="bracket every kernel of every Nth timed step with HIP events (1 = every step)")
@@ -165,6 +167,9 @@ def main():
         ctx.set_option("exact", 1)
     if args.chunk:
         ctx.set_option("chunk", args.chunk)
+    for o in args.opt:
+        name, val = o.split("=")
+        ctx.set_option(name, int(val))
     ctx.analysis_reset(W, H)
     hist_words = ctx.histogram_words()
     use_cabi = multi and args.collective == "rccl" and not rehearse

@@ -1199,6 +1199,116 @@ __device__ __forceinline__ void rc_rr_exchange(const float (&m)[NIT][5], float* 
     }
 }
 
+// flow_in of a thread's NIT grid positions (column gxo, rows gys[]): zeros at the coarsest scale, the previous
+// iteration's field, or resize(prevFlow, INTER_LINEAR) * (1 / pyr_scale) of the coarser scale (optflow.cpp calc()).
+// Shared by the register-row kernels, so they all see the same bits.
+// INTERIOR (k_flow_iter2_rrc: the block's M grid lies at least 5 px inside the image): no coordinate of the block
+// is clamped and offsets are 32-bit -- the same loads and the same arithmetic with fewer address instructions.
+template <int IN_MODE, int NIT, int MW, int MH, bool INTERIOR = false>
+__device__ __forceinline__ void rc_rr_flow_in(const RcIterArgs& a, const float2* __restrict__ fin, int tx0, int ty0,
+                                              int gxo, const int (&gys)[NIT], float (&dx)[NIT], float (&dy)[NIT]) {
+    const int w = a.w, h = a.h;
+    if constexpr (IN_MODE == 0) {
+#pragma unroll
+        for (int q = 0; q < NIT; q++) dx[q] = dy[q] = 0.f;
+    } else if constexpr (IN_MODE == 1) {
+        float2 d[NIT];
+#pragma unroll
+        for (int q = 0; q < NIT; q++) d[q] = INTERIOR ? fin[(unsigned)(gys[q] * w + gxo)] : fin[(size_t)gys[q] * w + gxo];
+#pragma unroll
+        for (int q = 0; q < NIT; q++) { dx[q] = d[q].x; dy[q] = d[q].y; }
+    } else if ((NIT % 2 == 0) && a.up_exact2 && (INTERIOR || (ty0 - 2 >= 0 && ty0 - 2 + MH <= h))) {
+        // Exactly half-size coarse scale, no row of the block clamped: the thread's first row is even, so
+        // its NIT rows read coarse rows rb .. rb + NIT/2 + 1 with rb = row/2 - 1 (row q: rb + (q+1)/2 and the
+        // next, fraction 0.75 / 0.25 for even / odd q).  Each coarse row is loaded and interpolated
+        // horizontally once instead of once per output row: NIT + 4 loads instead of 4 NIT, same values.
+        constexpr int NR = NIT / 2 + 2;
+        int sx = (gxo - 1) >> 1;
+        float ax = (gxo & 1) ? 0.25f : 0.75f;
+        if (!INTERIOR) {
+            if (sx < 0) { ax = 0.f; sx = 0; }
+            if (sx >= a.fin_w - 1) { ax = 0.f; sx = a.fin_w - 1; }
+        }
+        const int sx1 = min(sx + 1, a.fin_w - 1);
+        const int rb = (gys[0] - 1) >> 1;
+        float2 t0[NR], t1[NR];
+        // no column of the block clamped either: texels sx and sx + 1 are one 16-byte load (8-byte aligned)
+        typedef float rc_f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+        const bool cols_plain = INTERIOR || (tx0 - 2 >= 1 && tx0 - 2 + MW <= w && ((tx0 - 2 + MW - 2) >> 1) + 1 <= a.fin_w - 1);
+        if (INTERIOR) {
+            // (an interior block's coarse rows rb .. rb + NR - 1 and columns sx, sx + 1 all exist)
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const rc_f4a8 v = *(const rc_f4a8*)(fin + (unsigned)((rb + j) * a.fin_w + sx));
+                t0[j] = make_float2(v.x, v.y); t1[j] = make_float2(v.z, v.w);
+            }
+        } else if (cols_plain) {
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const float2* S = fin + (size_t)rc_clampi(rb + j, 0, a.fin_h - 1) * a.fin_w;
+                const rc_f4a8 v = *(const rc_f4a8*)(S + sx);
+                t0[j] = make_float2(v.x, v.y); t1[j] = make_float2(v.z, v.w);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const float2* S = fin + (size_t)rc_clampi(rb + j, 0, a.fin_h - 1) * a.fin_w;
+                t0[j] = S[sx]; t1[j] = S[sx1];
+            }
+        }
+        const float a0 = 1.f - ax, a1 = ax;
+        float hx[NR], hy[NR];
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            hx[j] = t0[j].x * a0 + t1[j].x * a1;
+            hy[j] = t0[j].y * a0 + t1[j].y * a1;
+        }
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            const int j0 = (q + 1) >> 1;
+            const float b1 = (q & 1) ? 0.25f : 0.75f, b0 = 1.f - b1;
+            dx[q] = (hx[j0] * b0 + hx[j0 + 1] * b1) * a.up_mul;
+            dy[q] = (hy[j0] * b0 + hy[j0 + 1] * b1) * a.up_mul;
+        }
+    } else {
+        float2 p00[NIT], p01[NIT], p10[NIT], p11[NIT];
+        float ax, ay[NIT];
+        int sx, sys[NIT];
+        if (a.up_exact2) {
+            // exactly half-size coarse scale: (d + 0.5) * 0.5 - 0.5 = d/2 - 0.25 in closed form
+            // (floor = (d - 1) >> 1, fraction 0.75 for even d, 0.25 for odd d): same values as
+            // rc_src_x / rc_src_y without the double arithmetic
+            sx = (gxo - 1) >> 1;
+            ax = (gxo & 1) ? 0.25f : 0.75f;
+            if (sx < 0) { ax = 0.f; sx = 0; }
+            if (sx >= a.fin_w - 1) { ax = 0.f; sx = a.fin_w - 1; }
+#pragma unroll
+            for (int q = 0; q < NIT; q++) { sys[q] = (gys[q] - 1) >> 1; ay[q] = (gys[q] & 1) ? 0.25f : 0.75f; }
+        } else {
+            sx = rc_src_x(gxo, a.up_scale_x, a.fin_w, ax);
+#pragma unroll
+            for (int q = 0; q < NIT; q++) sys[q] = rc_src_y(gys[q], a.up_scale_y, ay[q]);
+        }
+        const int sx1 = min(sx + 1, a.fin_w - 1);
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            int sy = sys[q];
+            int sy0 = rc_clampi(sy, 0, a.fin_h - 1), sy1 = rc_clampi(sy + 1, 0, a.fin_h - 1);
+            const float2* S0 = fin + (size_t)sy0 * a.fin_w;
+            const float2* S1 = fin + (size_t)sy1 * a.fin_w;
+            p00[q] = S0[sx]; p01[q] = S0[sx1]; p10[q] = S1[sx]; p11[q] = S1[sx1];
+        }
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            float a0 = 1.f - ax, a1 = ax, b0 = 1.f - ay[q], b1 = ay[q];
+            float r0x = p00[q].x * a0 + p01[q].x * a1, r1x = p10[q].x * a0 + p11[q].x * a1;
+            float r0y = p00[q].y * a0 + p01[q].y * a1, r1y = p10[q].y * a0 + p11[q].y * a1;
+            dx[q] = (r0x * b0 + r1x * b1) * a.up_mul;
+            dy[q] = (r0y * b0 + r1y * b1) * a.up_mul;
+        }
+    }
+}
+
 template <int IN_MODE, int GAUSS_, int NIT, int D, int MINB, int MW, int NG>
 __global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
     constexpr int NT = NG * MW, MH = NG * NIT, TW = MW - 4, TH = MH - 4;    // NG groups of NIT rows, MW columns
@@ -1285,96 +1395,7 @@ __global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
 #endif
     }
     float dx[NIT], dy[NIT];
-    if constexpr (IN_MODE == 0) {
-#pragma unroll
-        for (int q = 0; q < NIT; q++) dx[q] = dy[q] = 0.f;
-    } else if constexpr (IN_MODE == 1) {
-        float2 d[NIT];
-#pragma unroll
-        for (int q = 0; q < NIT; q++) d[q] = fin[(size_t)gys[q] * w + gxo];
-#pragma unroll
-        for (int q = 0; q < NIT; q++) { dx[q] = d[q].x; dy[q] = d[q].y; }
-    } else if ((NIT % 2 == 0) && a.up_exact2 && ty0 - 2 >= 0 && ty0 - 2 + MH <= h) {
-        // Exactly half-size coarse scale, no row of the block clamped: the thread's first row is even, so
-        // its NIT rows read coarse rows rb .. rb + NIT/2 + 1 with rb = row/2 - 1 (row q: rb + (q+1)/2 and the
-        // next, fraction 0.75 / 0.25 for even / odd q).  Each coarse row is loaded and interpolated
-        // horizontally once instead of once per output row: NIT + 4 loads instead of 4 NIT, same values.
-        constexpr int NR = NIT / 2 + 2;
-        int sx = (gxo - 1) >> 1;
-        float ax = (gxo & 1) ? 0.25f : 0.75f;
-        if (sx < 0) { ax = 0.f; sx = 0; }
-        if (sx >= a.fin_w - 1) { ax = 0.f; sx = a.fin_w - 1; }
-        const int sx1 = min(sx + 1, a.fin_w - 1);
-        const int rb = (gys[0] - 1) >> 1;
-        float2 t0[NR], t1[NR];
-        // no column of the block clamped either: texels sx and sx + 1 are one 16-byte load (8-byte aligned)
-        typedef float rc_f4a8 __attribute__((ext_vector_type(4), aligned(8)));
-        const bool cols_plain = tx0 - 2 >= 1 && tx0 - 2 + MW <= w && ((tx0 - 2 + MW - 2) >> 1) + 1 <= a.fin_w - 1;
-        if (cols_plain) {
-#pragma unroll
-            for (int j = 0; j < NR; j++) {
-                const float2* S = fin + (size_t)rc_clampi(rb + j, 0, a.fin_h - 1) * a.fin_w;
-                const rc_f4a8 v = *(const rc_f4a8*)(S + sx);
-                t0[j] = make_float2(v.x, v.y); t1[j] = make_float2(v.z, v.w);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NR; j++) {
-                const float2* S = fin + (size_t)rc_clampi(rb + j, 0, a.fin_h - 1) * a.fin_w;
-                t0[j] = S[sx]; t1[j] = S[sx1];
-            }
-        }
-        const float a0 = 1.f - ax, a1 = ax;
-        float hx[NR], hy[NR];
-#pragma unroll
-        for (int j = 0; j < NR; j++) {
-            hx[j] = t0[j].x * a0 + t1[j].x * a1;
-            hy[j] = t0[j].y * a0 + t1[j].y * a1;
-        }
-#pragma unroll
-        for (int q = 0; q < NIT; q++) {
-            const int j0 = (q + 1) >> 1;
-            const float b1 = (q & 1) ? 0.25f : 0.75f, b0 = 1.f - b1;
-            dx[q] = (hx[j0] * b0 + hx[j0 + 1] * b1) * a.up_mul;
-            dy[q] = (hy[j0] * b0 + hy[j0 + 1] * b1) * a.up_mul;
-        }
-    } else {
-        float2 p00[NIT], p01[NIT], p10[NIT], p11[NIT];
-        float ax, ay[NIT];
-        int sx, sys[NIT];
-        if (a.up_exact2) {
-            // exactly half-size coarse scale: (d + 0.5) * 0.5 - 0.5 = d/2 - 0.25 in closed form
-            // (floor = (d - 1) >> 1, fraction 0.75 for even d, 0.25 for odd d): same values as
-            // rc_src_x / rc_src_y without the double arithmetic
-            sx = (gxo - 1) >> 1;
-            ax = (gxo & 1) ? 0.25f : 0.75f;
-            if (sx < 0) { ax = 0.f; sx = 0; }
-            if (sx >= a.fin_w - 1) { ax = 0.f; sx = a.fin_w - 1; }
-#pragma unroll
-            for (int q = 0; q < NIT; q++) { sys[q] = (gys[q] - 1) >> 1; ay[q] = (gys[q] & 1) ? 0.25f : 0.75f; }
-        } else {
-            sx = rc_src_x(gxo, a.up_scale_x, a.fin_w, ax);
-#pragma unroll
-            for (int q = 0; q < NIT; q++) sys[q] = rc_src_y(gys[q], a.up_scale_y, ay[q]);
-        }
-        const int sx1 = min(sx + 1, a.fin_w - 1);
-#pragma unroll
-        for (int q = 0; q < NIT; q++) {
-            int sy = sys[q];
-            int sy0 = rc_clampi(sy, 0, a.fin_h - 1), sy1 = rc_clampi(sy + 1, 0, a.fin_h - 1);
-            const float2* S0 = fin + (size_t)sy0 * a.fin_w;
-            const float2* S1 = fin + (size_t)sy1 * a.fin_w;
-            p00[q] = S0[sx]; p01[q] = S0[sx1]; p10[q] = S1[sx]; p11[q] = S1[sx1];
-        }
-#pragma unroll
-        for (int q = 0; q < NIT; q++) {
-            float a0 = 1.f - ax, a1 = ax, b0 = 1.f - ay[q], b1 = ay[q];
-            float r0x = p00[q].x * a0 + p01[q].x * a1, r1x = p10[q].x * a0 + p11[q].x * a1;
-            float r0y = p00[q].y * a0 + p01[q].y * a1, r1y = p10[q].y * a0 + p11[q].y * a1;
-            dx[q] = (r0x * b0 + r1x * b1) * a.up_mul;
-            dy[q] = (r0y * b0 + r1y * b1) * a.up_mul;
-        }
-    }
+    rc_rr_flow_in<IN_MODE, NIT, MW, MH>(a, fin, tx0, ty0, gxo, gys, dx, dy);
     __syncthreads();      // (drains the LDS-DMA)
 #if RC_RR_PRIO == 4 || RC_RR_PRIO == 5
     __builtin_amdgcn_s_setprio(RC_RR_PRIO == 4 ? 0 : 3);
@@ -1460,6 +1481,297 @@ static void launch_rr_t(RcIterArgs a, int pairs, hipStream_t s) {
     if (const char* pad = getenv("RC_RR_LDS_PAD_KB")) lds += (size_t)atoi(pad) * 1024;      // occupancy experiment: fewer blocks per CU
     RC_ALLOW_LDS((k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB, MW, NG>), lds);
     hipLaunchKernelGGL((k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB, MW, NG>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(NG * MW), lds, s, a);
+}
+
+
+// ---- k_flow_iter2_rrc: the register-row kernel walking a CHAIN of consecutive frame pairs on one tile.
+// Pair z + 1's "previous" expansion R0 is pair z's "next" expansion R1 (the reference's u_f1.copyTo(u_f2),
+// ripcurrents.cpp:194-221, at tile level): when the block has finished the gathers of pair z, each thread takes
+// its NIT texels of R1 at its own grid positions out of the LDS window into the registers that held R0 -- the
+// next pair then needs only its own R1 window (LDS-DMA), its coarse flow and nothing of R0 from memory:
+// HBM and L2 reads per pixel drop from R0 20 + R1 20 to R1 20 (+ 20 / chain).  The window's DMA for pair z + 1
+// is issued as soon as the window of pair z is dead, ahead of pair z's last window sums, solve and stores.
+// The DMA goes out from inline asm and the barriers inside the loop wait for LDS traffic only (the compiler
+// would otherwise drain the outstanding DMA before every LDS read); one s_waitcnt vmcnt(0) per pair, at the
+// top of the loop, closes it.  Same arithmetic per pixel as k_flow_iter2_rr: bit-identical.
+__device__ __forceinline__ void rc_glds16_asm(const void* g, const void* lds_wave_base);
+__device__ __forceinline__ void rc_glds4_asm(const void* g, const void* lds_wave_base);
+__device__ __forceinline__ void rc_lds_barrier();
+__device__ __forceinline__ void rc_all_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// LDS-DMA with a wave-uniform base in SGPRs, a 32-bit byte offset per lane and the wave's LDS destination as a
+// plain byte address in M0 (no 64-bit address arithmetic, no generic-pointer casts).
+__device__ __forceinline__ void rc_glds16_s(const void* base, unsigned voff, uint32_t lds_wave_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_wave_addr) : "memory");
+}
+__device__ __forceinline__ void rc_glds4_s(const void* base, unsigned voff, uint32_t lds_wave_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(base), "s"(lds_wave_addr) : "memory");
+}
+
+// The R1 window of one pair: texel idx = tid + q NT of the [WH][WP] window, q = 0 .. NWL - 1.  (wy, wx) and the
+// texel's image offset advance by NT = QY WP + QX per step instead of being divided out each time.
+// lds_a / lds_b: LDS byte addresses of the window's float4 plane and float plane.
+template <bool INTERIOR, int NT, int WP, int WN, int NWL>
+__device__ __forceinline__ void rc_rrc_issue_window(const float4* __restrict__ RA1, const float* __restrict__ RB1,
+                                                    uint32_t lds_a, uint32_t lds_b, int tid, int ox, int oy, int w, int h) {
+    constexpr int QY = NT / WP, QX = NT % WP;
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+    int wy = tid / WP, wx = tid - wy * WP;
+    int off = (oy + wy) * w + ox + wx;
+#pragma unroll
+    for (int q = 0; q < NWL; q++) {
+        bool ok = (q + 1) * NT <= WN || tid + q * NT < WN;
+        if (!INTERIOR) ok = ok && (unsigned)(ox + wx) < (unsigned)w && (unsigned)(oy + wy) < (unsigned)h;
+        const unsigned p = ok ? (unsigned)off : 0u;     // out-of-image texels are never read
+        if (q * NT + wave_base < WN) {
+            rc_glds16_s(RA1, p << 4, lds_a + (uint32_t)(q * NT + wave_base) * 16u);
+            rc_glds4_s(RB1, p << 2, lds_b + (uint32_t)(q * NT + wave_base) * 4u);
+        }
+        wx += QX; wy += QY; off += QY * w + QX;
+        if (wx >= WP) { wx -= WP; wy += 1; off += w - WP; }
+    }
+}
+
+// FarnebackUpdateMatrices at a thread's NIT grid positions.  Interior blocks (the whole M grid at least 5 px
+// inside the image: no border factors, no clamped coordinates, and a sample inside the window is inside the
+// image) take a straight-line path: every lane gathers from the LDS window at an index clamped into it, and a
+// lane whose displacement leaves the window (|flow| >= D, rare) is redone from global memory afterwards.  The
+// values are those of rc_gather_window + rc_matrices_reg, which border blocks keep using: same bits.
+#ifndef RC_RRC_ABL
+#define RC_RRC_ABL 0      // timing-only cuts of k_flow_iter2_rrc (never in the product): 1 = no window DMA after the head of a chain, 2 = the loads alone
+#endif
+template <bool INTERIOR, int NIT, int WW, int WH, int WP>
+__device__ __forceinline__ void rc_rr_matrices(float (&m)[NIT][5], const float4 (&A0)[NIT], const float (&B0)[NIT],
+                                               const float (&dx)[NIT], const float (&dy)[NIT], const float4* LA,
+                                               const float* LB, int ox, int oy, const float4* __restrict__ RA1,
+                                               const float* __restrict__ RB1, int gxo, const int (&gys)[NIT], int w, int h) {
+    if constexpr (!INTERIOR) {
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            RcGather g;
+            rc_gather_window<WW, WH, WP>(g, LA, LB, ox, oy, RA1, RB1, gxo, gys[q], dx[q], dy[q], w, h);
+            RcM5 v = rc_matrices_reg(A0[q], B0[q], g, dx[q], dy[q], gxo, gys[q], w, h, true);
+            m[q][0] = v.m0; m[q][1] = v.m1; m[q][2] = v.m2; m[q][3] = v.m3; m[q][4] = v.m4;
+        }
+    } else {
+        unsigned far = 0;
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            RcGather g;
+            const float fx = gxo + dx[q], fy = gys[q] + dy[q];
+            const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+            g.fx = fx - x1;
+            g.fy = fy - y1;
+            g.inside = true;
+            const int wx = x1 - ox, wy = y1 - oy;
+            const bool in_win = (unsigned)wx < (unsigned)(WW - 1) && (unsigned)wy < (unsigned)(WH - 1);
+            far |= in_win ? 0u : 1u << q;
+            const int i = in_win ? wy * WP + wx : 0;
+            g.q00 = LA[i]; g.q01 = LA[i + 1]; g.q10 = LA[i + WP]; g.q11 = LA[i + WP + 1];
+            g.e00 = LB[i]; g.e01 = LB[i + 1]; g.e10 = LB[i + WP]; g.e11 = LB[i + WP + 1];
+            RcM5 v = rc_matrices_reg(A0[q], B0[q], g, dx[q], dy[q], gxo, gys[q], w, h, false);
+            m[q][0] = v.m0; m[q][1] = v.m1; m[q][2] = v.m2; m[q][3] = v.m3; m[q][4] = v.m4;
+        }
+        if (__builtin_expect(far != 0, 0)) {
+#pragma unroll
+            for (int q = 0; q < NIT; q++) {
+                if (far >> q & 1) {
+                    RcGather g;
+                    rc_gather_issue(g, RA1, RB1, gxo, gys[q], dx[q], dy[q], w, h);
+                    RcM5 v = rc_matrices_reg(A0[q], B0[q], g, dx[q], dy[q], gxo, gys[q], w, h, false);
+                    m[q][0] = v.m0; m[q][1] = v.m1; m[q][2] = v.m2; m[q][3] = v.m3; m[q][4] = v.m4;
+                }
+            }
+        }
+    }
+}
+
+template <bool INTERIOR, int IN_MODE, int GAUSS_, int NIT, int D, int MW, int NG>
+__device__ __forceinline__ void rc_rrc_body(const RcIterArgs& a, const int zb, const int ze, float* smf, const uint32_t lds0, const int tx0, const int ty0) {
+    constexpr int NT = NG * MW, MH = NG * NIT;
+    constexpr int WW = MW + 2 * D, WH = MH + 2 * D, WP = WW, WN = WP * WH, NWL = (WN + NT - 1) / NT;
+    constexpr int WNP = (WN + 63) & ~63;
+    constexpr int MP = MW + 1, PLANE = MH * MP;
+    static_assert(5 * PLANE <= 5 * WNP, "border-block M1 planes alias the R1 window");
+    float4* LA = (float4*)smf;              // [WH][WW]  R1 (y, x, yy, xx)
+    float* LB = smf + 4 * WNP;              // [WH][WW]  R1 xy
+    float* XR = LB + WNP;                   // [NG][2][5][MW] first / last row of every group
+    float* Ms = smf;                        // border blocks only: [5][MH][MP], after the window is dead
+    const uint32_t lds_a = lds0, lds_b = lds0 + 16u * WNP;     // LDS byte addresses of LA and LB
+    const int w = a.w, h = a.h;
+    const int ox = tx0 - 2 - D, oy = ty0 - 2 - D;
+    // Everything a thread derives from its index (grid position, clamped coordinates, DMA / coarse-flow / store
+    // addresses) is re-derived per pair from an index the compiler cannot see through: hoisted out of the loop
+    // these invariants cost ~60 registers and spill, recomputed they cost a few instructions.
+#define RC_RRC_COORDS(tid_)                                                         \
+    const int x = (tid_) & (MW - 1), grp = (tid_) / MW, ly0 = grp * NIT;            \
+    const int px = tx0 - 2 + x;                                                     \
+    const int gxo = INTERIOR ? px : rc_clampi(px, 0, w - 1);                        \
+    int gys[NIT];                                                                   \
+    _Pragma("unroll") for (int q = 0; q < NIT; q++)                                 \
+        gys[q] = INTERIOR ? ty0 - 2 + ly0 + q : rc_clampi(ty0 - 2 + ly0 + q, 0, h - 1);
+
+    // ---- head of the chain: the window of pair zb, R0 from memory, flow_in of pair zb
+    float4 A0[NIT];
+    float B0[NIT];
+    float dx[NIT], dy[NIT];
+    {
+        const int tid = threadIdx.x;
+        RC_RRC_COORDS(tid)
+        const size_t s0 = (size_t)((a.slot0 + zb * a.zstep) % a.nslots) * a.R_slot_stride;
+        const size_t s1 = (size_t)((a.slot1 + zb * a.zstep) % a.nslots) * a.R_slot_stride;
+        rc_rrc_issue_window<INTERIOR, NT, WP, WN, NWL>(a.RA + s1, a.RB + s1, lds_a, lds_b, tid, ox, oy, w, h);
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            const unsigned p0 = (unsigned)(gys[q] * w + gxo);
+            A0[q] = (a.RA + s0)[p0];
+            B0[q] = (a.RB + s0)[p0];
+        }
+        rc_rr_flow_in<IN_MODE, NIT, MW, MH, INTERIOR>(a, a.fin + (size_t)zb * a.fin_pair_stride, tx0, ty0, gxo, gys, dx, dy);
+    }
+
+    for (int z = zb; z < ze; z++) {
+        const size_t s1 = (size_t)((a.slot1 + z * a.zstep) % a.nslots) * a.R_slot_stride;
+        const float4* __restrict__ RA1 = a.RA + s1;
+        const float* __restrict__ RB1 = a.RB + s1;
+        const bool more = z + 1 < ze;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        RC_RRC_COORDS(tid)
+        rc_all_barrier();     // this pair's window has landed (and the previous pair's exchange rows are dead)
+#if RC_RRC_ABL == 2
+        if (a.w > 0) {        // timing-only build: the loads and the hand-over alone
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < NIT; q++) {
+                    const int i = (gys[q] - oy) * WP + (gxo - ox);
+                    A0[q].x += LA[i].x + LA[i].w;
+                    B0[q] += LB[i];
+                }
+                rc_lds_barrier();
+                const size_t n1 = (size_t)((a.slot1 + (z + 1) * a.zstep) % a.nslots) * a.R_slot_stride;
+                rc_rrc_issue_window<INTERIOR, NT, WP, WN, NWL>(a.RA + n1, a.RB + n1, lds_a, lds_b, tid, ox, oy, w, h);
+                rc_rr_flow_in<IN_MODE, NIT, MW, MH, INTERIOR>(a, a.fin + (size_t)(z + 1) * a.fin_pair_stride, tx0, ty0, gxo, gys, dx, dy);
+            } else {
+                float acc = dx[0] + dy[NIT - 1];
+#pragma unroll
+                for (int q = 0; q < NIT; q++) acc += A0[q].x + A0[q].w + B0[q];
+                if (acc == 12345.678f) *(float*)a.fout = acc;
+            }
+            continue;
+        }
+#endif
+
+        // ---- M0 on the whole grid, in registers
+        float m[NIT][5];
+        rc_rr_matrices<INTERIOR, NIT, WW, WH, WP>(m, A0, B0, dx, dy, LA, LB, ox, oy, RA1, RB1, gxo, gys, w, h);
+        rc_rr_exchange<NIT, MW>(m, XR, grp, x);
+        rc_lds_barrier();
+
+        // ---- flow1, then M1 in place of M0
+        {
+            float2 f1[NIT];
+            rc_rr_flows<GAUSS_, NIT, MW, NG>(m, XR, grp, x, a.win, f1);
+            float f1x[NIT], f1y[NIT];
+#pragma unroll
+            for (int q = 0; q < NIT; q++) { f1x[q] = f1[q].x; f1y[q] = f1[q].y; }
+            rc_rr_matrices<INTERIOR, NIT, WW, WH, WP>(m, A0, B0, f1x, f1y, LA, LB, ox, oy, RA1, RB1, gxo, gys, w, h);
+        }
+        // ---- the hand-over: this pair's R1 at the thread's own (clamped) grid positions is the next pair's R0
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < NIT; q++) {
+                const int i = (gys[q] - oy) * WP + (gxo - ox);
+                A0[q] = LA[i];
+                B0[q] = LB[i];
+            }
+        }
+        rc_lds_barrier();     // the exchange rows and the R1 window have been read by everyone
+        if constexpr (!INTERIOR) {
+            // A grid position outside the image stands for the border pixel it replicates (the window's
+            // replicate border): take that pixel's M1
+#pragma unroll
+            for (int q = 0; q < NIT; q++)
+#pragma unroll
+                for (int c = 0; c < 5; c++) Ms[c * PLANE + (ly0 + q) * MP + x] = m[q][c];
+            rc_lds_barrier();
+#pragma unroll
+            for (int q = 0; q < NIT; q++) {
+                const int py = ty0 - 2 + ly0 + q;
+                if ((unsigned)px >= (unsigned)w || (unsigned)py >= (unsigned)h) {
+                    const int cx = gxo - (tx0 - 2), cy = gys[q] - (ty0 - 2);
+#pragma unroll
+                    for (int c = 0; c < 5; c++) m[q][c] = Ms[c * PLANE + cy * MP + cx];
+                }
+            }
+        }
+        rc_rr_exchange<NIT, MW>(m, XR, grp, x);
+        rc_lds_barrier();     // (border blocks: the aliased M1 planes have been read by everyone too)
+
+        // ---- the next pair's window is requested before this pair's last window sums, solve and stores
+#if RC_RRC_ABL != 1
+        if (more) {
+            const size_t n1 = (size_t)((a.slot1 + (z + 1) * a.zstep) % a.nslots) * a.R_slot_stride;
+            rc_rrc_issue_window<INTERIOR, NT, WP, WN, NWL>(a.RA + n1, a.RB + n1, lds_a, lds_b, tid, ox, oy, w, h);
+        }
+#endif
+
+        // ---- flow2 on the tile
+        {
+            char* fout = a.fout + (size_t)z * a.fout_pair_stride;
+            float2 f2[NIT];
+            rc_rr_flows<GAUSS_, NIT, MW, NG>(m, XR, grp, x, a.win, f2);
+            if (x >= 2 && x < MW - 2 && (INTERIOR || px < w)) {
+#pragma unroll
+                for (int q = 0; q < NIT; q++) {
+                    const int ly = ly0 + q, py = ty0 - 2 + ly;
+                    if (ly >= 2 && ly < MH - 2 && (INTERIOR || py < h))
+                        *(float2*)(fout + ((unsigned)py * (unsigned)a.fout_step + (unsigned)px * 8u)) = f2[q];   // (a.addr32)
+                }
+            }
+        }
+        if (more) rc_rr_flow_in<IN_MODE, NIT, MW, MH, INTERIOR>(a, a.fin + (size_t)(z + 1) * a.fin_pair_stride, tx0, ty0, gxo, gys, dx, dy);
+    }
+#undef RC_RRC_COORDS
+}
+
+template <int IN_MODE, int GAUSS_, int NIT, int D, int MINB, int MW, int NG>
+__global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rrc(RcIterArgs a, RcChainPlan cp) {
+    constexpr int MH = NG * NIT, TW = MW - 4, TH = MH - 4;
+    extern __shared__ __align__(16) float smf[];
+    const int zb = cp.start[blockIdx.y], ze = cp.start[blockIdx.y + 1];
+    const int t = a.xcd_remap ? rc_xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y) : (int)blockIdx.x;
+    const int tx0 = (t % a.tiles_x) * TW, ty0 = (t / a.tiles_x) * TH;
+    const bool interior = tx0 - 2 >= 5 && tx0 - 2 + MW <= a.w - 5 && ty0 - 2 >= 5 && ty0 - 2 + MH <= a.h - 5;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smf;
+    if (interior) rc_rrc_body<true, IN_MODE, GAUSS_, NIT, D, MW, NG>(a, zb, ze, smf, lds0, tx0, ty0);
+    else rc_rrc_body<false, IN_MODE, GAUSS_, NIT, D, MW, NG>(a, zb, ze, smf, lds0, tx0, ty0);
+}
+
+template <int IN_MODE, int G, int NIT, int D, int MINB, int MW = 32, int NG = 8>
+static void launch_rrc_t(RcIterArgs a, const RcChainPlan& cp, hipStream_t s) {
+    constexpr int MH = NG * NIT, TW = MW - 4, TH = MH - 4;
+    a.tw = TW; a.th = TH;
+    a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
+    constexpr int WN = (MW + 2 * D) * (MH + 2 * D), WNP = (WN + 63) & ~63;
+    const size_t lds = sizeof(float) * (5 * WNP + NG * 2 * 5 * MW);
+    RC_ALLOW_LDS((k_flow_iter2_rrc<IN_MODE, G, NIT, D, MINB, MW, NG>), lds);
+    hipLaunchKernelGGL((k_flow_iter2_rrc<IN_MODE, G, NIT, D, MINB, MW, NG>), dim3(a.tiles_x * a.tiles_y, cp.ngroups, 1), dim3(NG * MW), lds, s, a, cp);
+}
+
+// Chain groups of a launch of `pairs` consecutive pairs: runs of `chain` pairs, then halving runs over the last
+// `chain` pairs (8, 8, 8, 4, 2, 1, 1 for 32 pairs and chain 8) so that the blocks still running when the grid
+// drains are short ones -- a long-lived block in the last wave of a launch idles the rest of the GPU.
+static void rc_chain_plan(int pairs, int chain, RcChainPlan& cp) {
+    int n = 0, z = 0;
+    cp.start[0] = 0;
+    while (z < pairs) {
+        int left = pairs - z, c = left > chain ? chain : (left + 1) / 2;
+        if (n == RC_MAX_CHAIN_GROUPS - 1) c = left;
+        z += c;
+        cp.start[++n] = z;
+    }
+    cp.ngroups = n;
 }
 
 
@@ -1869,9 +2181,19 @@ static void launch_w3x2(RcIterArgs a, int pairs, hipStream_t s) {
         // A launch of fewer blocks than the GPU holds at once (1024 = 256 CUs x 4) lasts one block's
         // lifetime: shorter tiles then finish sooner (frame-at-a-time calls, coarse scales).  Same bits.
         const long long blocks = (long long)((a.w + 27) / 28) * ((a.h + 27) / 28) * pairs;
-        if (blocks < 512) launch_rr_t<IN_MODE, G, 2, 4, 6>(a, pairs, s);          // 28x12 tile
+        // consecutive pairs of one stream (pair z + 1's previous frame is pair z's next frame): tile chains
+        const bool chainable = a.chain > 1 && pairs > 1 && a.addr32 && (a.slot0 + a.zstep) % a.nslots == a.slot1 % a.nslots;
+        if (chainable && (a.ablate & RC_ABL_FORCE_CHAIN)) {
+            RcChainPlan cp;
+            rc_chain_plan(pairs, a.chain, cp);
+            launch_rrc_t<IN_MODE, G, 4, RC_RR_D, 4>(a, cp, s);
+        } else if (blocks < 512) launch_rr_t<IN_MODE, G, 2, 4, 6>(a, pairs, s);   // 28x12 tile
         else if (blocks < 1024) launch_rr_t<IN_MODE, G, 3, 4, 5>(a, pairs, s);    // 28x20 tile
-        else launch_rr_t<IN_MODE, G, 4, RC_RR_D, 4>(a, pairs, s);                 // 28x28 tile, 4 blocks per CU
+        else if (chainable && blocks >= 4096) {
+            RcChainPlan cp;
+            rc_chain_plan(pairs, a.chain, cp);
+            launch_rrc_t<IN_MODE, G, 4, RC_RR_D, 4>(a, cp, s);                    // 28x28 tile, chains of pairs
+        } else launch_rr_t<IN_MODE, G, 4, RC_RR_D, 4>(a, pairs, s);               // 28x28 tile, 4 blocks per CU
     }
 }
 

@@ -117,6 +117,7 @@ enum RcAblate : int {
     RC_ABL_TILE_WINDOW = 65536,      // Gaussian winsize 10 / 20: tile kernel even for large launches
     RC_ABL_SWEEP_512T = 131072,      // strip-sweep kernel with 512 threads
     RC_ABL_FORCE_SWEEP = 8388608,    // strip-sweep kernel even for small launches
+    RC_ABL_FORCE_CHAIN = 33554432,   // fused winsize-3 kernel: tile chains (option "chain") even for launches too small to want them
     RC_ABL_HIST_V1 = 16777216,       // histogram: the first form of the kernel (one scalar round per pixel, exact key everywhere)
 };
 
@@ -143,8 +144,17 @@ struct RcIterArgs {
     int solve;                // 0: write flow_in (iterations == 0), 1: normal
     int xcd_remap;            // XCD-aware tile order (speed only)
     int ablate;               // timing-only ablation bits (0 in production)
+    int addr32;               // every offset inside one frame's R planes and one pair's flow field fits 32 bits (set by the level driver)
+    int chain;                // option "chain": consecutive pairs a block of the fused winsize-3 kernel walks on its tile (<= 1: none)
     long long* stamps;        // diagnostic s_memtime stamps (null in production)
     RcWindow win;
+};
+
+// Pair groups of a chained launch (k_flow_iter2_rrc): block row g walks pairs start[g] .. start[g + 1] - 1.
+#define RC_MAX_CHAIN_GROUPS 40
+struct RcChainPlan {
+    int ngroups;
+    int start[RC_MAX_CHAIN_GROUPS + 1];
 };
 
 // Option "exact" (exact_kernels.hip): one scale of the upstream CPU operation order, staged through HBM.

@@ -93,6 +93,7 @@ struct rc_ctx {
     int exact_taps = 0;
     int exact = -1;            // option "exact": upstream's CPU operation order (exact_kernels.hip); -1 = where the fast path cannot hold the tolerance
     int fuse_iters = 1;
+    int chain = 8;             // option "chain": pairs per tile chain of the fused winsize-3 flow kernel (1 = off)
     int xcd_remap = 1;
     int poly_tile_h = 32;
     int frame_overlap = 1;     // option "frame_overlap": frame loop with the expansion of frame t+1 on a second stream beside the flow kernels of frame t

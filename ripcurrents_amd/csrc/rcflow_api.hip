@@ -277,6 +277,9 @@ extern "C" int rcflow_set_option(rc_ctx* ctx, const char* name, int value) {
         ctx->exact = value;
     } else if (!strcmp(name, "fuse_iters")) {
         ctx->fuse_iters = value ? 1 : 0;
+    } else if (!strcmp(name, "chain")) {
+        if (value < 1 || value > 64) return RC_EINVAL;
+        ctx->chain = value;
     } else if (!strcmp(name, "xcd_remap")) {
         ctx->xcd_remap = value ? 1 : 0;
     } else if (!strcmp(name, "hist_blocks")) {
@@ -764,6 +767,7 @@ static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_
         a.win = pl.win;
         a.xcd_remap = ctx->xcd_remap;
         a.ablate = ctx->ablate;
+        a.chain = ctx->chain;
         a.stamps = (k == 0) ? (long long*)ctx->stamps : nullptr;
         const float2* cur_in = nullptr;
         int passes = iters > 0 ? iters : 1;
@@ -796,6 +800,7 @@ static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_
                 a.fout = (char*)dst; a.fout_step = (size_t)L.w * 8; a.fout_pair_stride = n * 8;
                 cur_in = dst;
             }
+            a.addr32 = n * 16 < (1ull << 32) && (size_t)L.h * a.fout_step < (1ull << 32);
             {
                 // SURVEY 8(d) bytes of the stages this launch stands for: the first launch of a scale
                 // carries "init matrices" (8 N_{k+1} + 60 N_k), every iteration but the last 80 N_k

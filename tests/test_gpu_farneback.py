@@ -356,6 +356,46 @@ def test_chunk_option_invariance(ctx):
     ctx.set_option("chunk", 32)
 
 
+@pytest.mark.parametrize("size,params,T", [((640, 480), dict(levels=2), 10), ((333, 251), dict(levels=2, flags=256), 7),
+                                           ((1024, 576), dict(levels=4), 6), ((700, 500), dict(pyr_scale=0.7, levels=3), 6),
+                                           ((257, 130), dict(levels=0, iterations=4), 12), ((1920, 1080), dict(levels=2), 10)])
+def test_tile_chains_same_bits(ctx, size, params, T):
+    """Option `chain`: a block of the fused winsize-3 kernel walks consecutive pairs on its tile and takes pair z + 1's R0
+    out of pair z's R1 window in LDS (k_flow_iter2_rrc; the reference's u_f1.copyTo(u_f2), ripcurrents.cpp:194-221, at tile
+    level).  Same bits as one pair per block for every chain length, border tiles, every flow_in form (zeros, previous
+    iteration, coarser scale at exact and inexact ratios), chain groups of unequal length and chunk ends (chunk 5 of 9 pairs)."""
+    w, h = size
+    p = dict(pyr_scale=0.5, levels=2, winsize=3, iterations=2, poly_n=15, poly_sigma=1.2, flags=0)
+    p.update(params)
+    clip = torch.as_tensor(synth.surf_clip(w, h, T, seed=11)).cuda()
+    ctx.set_option("exact", 0)
+    try:
+        ctx.set_option("chain", 1)
+        a = ctx.farneback_clip(clip, **p).clone()
+        assert torch.isfinite(a).all()
+        ctx.set_option("ablate", 33554432)       # RC_ABL_FORCE_CHAIN: chains whatever the launch size
+        for chain, chunk in ((2, 32), (3, 32), (4, 5), (8, 32), (64, 32)):
+            ctx.set_option("chain", chain)
+            ctx.set_option("chunk", chunk)
+            b = ctx.farneback_clip(clip, **p).clone()
+            assert torch.equal(a, b), "chain %d chunk %d" % (chain, chunk)
+        # the streaming entry point (a continuing segment: the slot ring wraps between calls)
+        ctx.set_option("chain", 4)
+        ctx.set_option("chunk", 4)
+        ctx.stream_reset()
+        out = torch.empty((T - 1, h, w, 2), dtype=torch.float32, device="cuda")
+        ctx.push_clip(clip[0:1], out, **p)
+        got = ctx.push_clip(clip[1:], out, **p)
+        ctx.sync()
+        assert got.shape[0] == T - 1 and torch.equal(a, got)
+    finally:
+        ctx.set_option("ablate", 0)
+        ctx.set_option("chain", 8)
+        ctx.set_option("chunk", 32)
+        ctx.set_option("exact", -1)
+        ctx.stream_reset()
+
+
 def test_full_size_1080p_parity(ctx, orc):
     """BASELINE config 2 at full size against the oracle (one pair, ~2 s of CPU)."""
     clip = synth.surf_clip(1920, 1080, 2, seed=1234)
