@@ -1739,7 +1739,8 @@ template <int IN_MODE, int GAUSS_, int NIT, int D, int MINB, int MW, int NG>
 __global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rrc(RcIterArgs a, RcChainPlan cp) {
     constexpr int MH = NG * NIT, TW = MW - 4, TH = MH - 4;
     extern __shared__ __align__(16) float smf[];
-    const int zb = cp.start[blockIdx.y], ze = cp.start[blockIdx.y + 1];
+    // (ngroups == 0: independent pairs, one per block row)
+    const int zb = cp.ngroups ? cp.start[blockIdx.y] : (int)blockIdx.y, ze = cp.ngroups ? cp.start[blockIdx.y + 1] : zb + 1;
     const int t = a.xcd_remap ? rc_xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y) : (int)blockIdx.x;
     const int tx0 = (t % a.tiles_x) * TW, ty0 = (t / a.tiles_x) * TH;
     const bool interior = tx0 - 2 >= 5 && tx0 - 2 + MW <= a.w - 5 && ty0 - 2 >= 5 && ty0 - 2 + MH <= a.h - 5;
@@ -1749,20 +1750,28 @@ __global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rrc(RcIterArgs a, 
 }
 
 template <int IN_MODE, int G, int NIT, int D, int MINB, int MW = 32, int NG = 8>
-static void launch_rrc_t(RcIterArgs a, const RcChainPlan& cp, hipStream_t s) {
+static void launch_rrc_t(RcIterArgs a, const RcChainPlan& cp, int pairs, hipStream_t s) {
     constexpr int MH = NG * NIT, TW = MW - 4, TH = MH - 4;
     a.tw = TW; a.th = TH;
     a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
     constexpr int WN = (MW + 2 * D) * (MH + 2 * D), WNP = (WN + 63) & ~63;
     const size_t lds = sizeof(float) * (5 * WNP + NG * 2 * 5 * MW);
     RC_ALLOW_LDS((k_flow_iter2_rrc<IN_MODE, G, NIT, D, MINB, MW, NG>), lds);
-    hipLaunchKernelGGL((k_flow_iter2_rrc<IN_MODE, G, NIT, D, MINB, MW, NG>), dim3(a.tiles_x * a.tiles_y, cp.ngroups, 1), dim3(NG * MW), lds, s, a, cp);
+    hipLaunchKernelGGL((k_flow_iter2_rrc<IN_MODE, G, NIT, D, MINB, MW, NG>), dim3(a.tiles_x * a.tiles_y, cp.ngroups ? cp.ngroups : pairs, 1), dim3(NG * MW), lds, s, a, cp);
 }
 
 // Chain groups of a launch of `pairs` consecutive pairs: runs of `chain` pairs, then halving runs over the last
 // `chain` pairs (8, 8, 8, 4, 2, 1, 1 for 32 pairs and chain 8) so that the blocks still running when the grid
-// drains are short ones -- a long-lived block in the last wave of a launch idles the rest of the GPU.
-static void rc_chain_plan(int pairs, int chain, RcChainPlan& cp) {
+// drains are short ones -- a long-lived block in the last wave of a launch idles the rest of the GPU.  The chain
+// is shortened until the launch still has ~8 blocks per block slot of the GPU (1024 = 256 CUs x 4).
+static void rc_chain_plan(const RcIterArgs& a, int pairs, long long tiles, RcChainPlan& cp) {
+    cp.ngroups = 0;
+    const bool chainable = a.chain > 1 && pairs > 1 && a.addr32 && (a.slot0 + a.zstep) % a.nslots == a.slot1 % a.nslots;
+    if (!chainable) return;
+    int chain = a.chain;
+    if (!(a.ablate & RC_ABL_FORCE_CHAIN))
+        while (chain > 1 && tiles * pairs / chain < 8192) chain >>= 1;
+    if (chain <= 1) return;
     int n = 0, z = 0;
     cp.start[0] = 0;
     while (z < pairs) {
@@ -1773,7 +1782,6 @@ static void rc_chain_plan(int pairs, int chain, RcChainPlan& cp) {
     }
     cp.ngroups = n;
 }
-
 
 // ---- k_flow_iter2_db: the register-row kernel with its loads taken out of the block's critical path.
 // A block of 512 threads (NG = 16 groups of NIT = 2 rows) walks `chain` consecutive tiles of one pair and keeps
@@ -2180,20 +2188,15 @@ static void launch_w3x2(RcIterArgs a, int pairs, hipStream_t s) {
     else {
         // A launch of fewer blocks than the GPU holds at once (1024 = 256 CUs x 4) lasts one block's
         // lifetime: shorter tiles then finish sooner (frame-at-a-time calls, coarse scales).  Same bits.
-        const long long blocks = (long long)((a.w + 27) / 28) * ((a.h + 27) / 28) * pairs;
+        const long long tiles = (long long)((a.w + 27) / 28) * ((a.h + 27) / 28), blocks = tiles * pairs;
         // consecutive pairs of one stream (pair z + 1's previous frame is pair z's next frame): tile chains
-        const bool chainable = a.chain > 1 && pairs > 1 && a.addr32 && (a.slot0 + a.zstep) % a.nslots == a.slot1 % a.nslots;
-        if (chainable && (a.ablate & RC_ABL_FORCE_CHAIN)) {
-            RcChainPlan cp;
-            rc_chain_plan(pairs, a.chain, cp);
-            launch_rrc_t<IN_MODE, G, 4, RC_RR_D, 4>(a, cp, s);
-        } else if (blocks < 512) launch_rr_t<IN_MODE, G, 2, 4, 6>(a, pairs, s);   // 28x12 tile
-        else if (blocks < 1024) launch_rr_t<IN_MODE, G, 3, 4, 5>(a, pairs, s);    // 28x20 tile
-        else if (chainable && blocks >= 4096) {
-            RcChainPlan cp;
-            rc_chain_plan(pairs, a.chain, cp);
-            launch_rrc_t<IN_MODE, G, 4, RC_RR_D, 4>(a, cp, s);                    // 28x28 tile, chains of pairs
-        } else launch_rr_t<IN_MODE, G, 4, RC_RR_D, 4>(a, pairs, s);               // 28x28 tile, 4 blocks per CU
+        RcChainPlan cp;
+        rc_chain_plan(a, pairs, tiles, cp);
+        if (!a.addr32) launch_rr_t<IN_MODE, G, 4, RC_RR_D, 4>(a, pairs, s);             // (64-bit offsets: the first form of the kernel)
+        else if (cp.ngroups) launch_rrc_t<IN_MODE, G, 4, RC_RR_D, 4>(a, cp, pairs, s);  // 28x28 tile, chains of pairs
+        else if (blocks < 512) launch_rrc_t<IN_MODE, G, 2, 4, 6>(a, cp, pairs, s);      // 28x12 tile
+        else if (blocks < 1024) launch_rrc_t<IN_MODE, G, 3, 4, 5>(a, cp, pairs, s);     // 28x20 tile
+        else launch_rrc_t<IN_MODE, G, 4, RC_RR_D, 4>(a, cp, pairs, s);                  // 28x28 tile, 4 blocks per CU
     }
 }
 

@@ -151,7 +151,7 @@ struct RcIterArgs {
 };
 
 // Pair groups of a chained launch (k_flow_iter2_rrc): block row g walks pairs start[g] .. start[g + 1] - 1.
-#define RC_MAX_CHAIN_GROUPS 40
+#define RC_MAX_CHAIN_GROUPS 64
 struct RcChainPlan {
     int ngroups;
     int start[RC_MAX_CHAIN_GROUPS + 1];
