@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of dense Farneback flow @1080p on N MI355X GPUs (BASELINE.json).
 
-  python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W [--repeats R]
+  N>1: either under the launcher (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...,
+  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or plainly -- without WORLD_SIZE in the
+  environment the script starts that launcher itself as a CHILD process before anything touches the GPU and
+  exits with its status.  The timed region (exactly K steps between barrier + synchronize on both sides, MAX over
+  ranks) is repeated R times; `value` is the median window, `value_min` / `value_max` the extremes.
 
 Workload (BASELINE config 2; config 4 when N>1): a synthetic 1920x1080 surf clip resident in
 HBM, 3 pyramid scales (levels=2), the parameter set of ripcurrents.cpp:215
@@ -49,7 +53,7 @@ def survey_model_bytes_per_frame(w, h, levels, iters):
     return total
 
 
-PMC_FILE = "profiles/r02_pmc_traffic.json"
+PMC_FILE = "profiles/r03_pmc_traffic.json"
 
 
 def pmc_traffic(kernel, args):
@@ -68,11 +72,62 @@ def pmc_traffic(kernel, args):
         return None, None, None
 
 
+def measured_memory_roof():
+    """Streaming read / write / copy rates of this device from scripts/diag/membw (a stand-alone HIP microbenchmark
+    built by __graft_entry__.build(), run as a child process after the timed region; 2 GiB buffers, beyond the
+    Infinity Cache).  None when the tool is absent or fails -- a yardstick next to the 8 TB/s spec, never the peak
+    `roofline.frac` is quoted on."""
+    import subprocess
+    tool = os.path.join(ROOT, "scripts", "diag", "membw")
+    if not os.path.exists(tool):
+        return None
+    try:
+        out = subprocess.run([tool, "--json"], capture_output=True, text=True, timeout=120).stdout
+        for line in out.splitlines():
+            if line.startswith("{"):
+                return json.loads(line)
+    except Exception:
+        pass
+    return None
+
+
+def launcher_command(argv, gpus, port=None):
+    """The child command a plain `python bench.py --gpus N` (N > 1, no WORLD_SIZE) starts: the same launcher line the
+    driver uses, one rank per GPU, rendezvous on 127.0.0.1."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % gpus,
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def device_identity(torch, dev):
+    """What tells two GPUs apart in a SCALE record: uuid and PCI location of the device this rank computes on."""
+    out = {"index": dev.index}
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        out["name"] = pr.name
+        u = getattr(pr, "uuid", None)
+        if u is not None:
+            out["uuid"] = str(u)
+        if hasattr(pr, "pci_bus_id"):
+            out["pci"] = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0))
+    except Exception as e:                      # identity is evidence, never a reason to fail the run
+        out["error"] = repr(e)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=15,
+                    help="the timed window of --steps steps is repeated this many times (each between barrier + synchronize); "
+                         "value = the median window")
+    ap.add_argument("--dry-launch", action="store_true", help="print the launcher command --gpus N would start, and exit")
     ap.add_argument("--warmup-seconds", type=float, default=1.0,
                     help="untimed steps continue after --warmup until this much time has passed (clocks and "
                          "caches at steady state however small --warmup is); 0 disables")
@@ -106,6 +161,23 @@ def main():
                          "buffer, flow stays on the device (rcflow_push_frame_u8; PCIe-inclusive upload); host-stateless = "
                          "the literal two-image drop-in with host pointers and the flow copied back (rcflow_farneback_u8)")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.repeats < 1:
+        ap.error("--gpus, --steps and --repeats must be positive")
+
+    # N > 1 without a launcher around us: start it as a child, BEFORE torch is imported or any GPU call is made (a
+    # process that has initialised the GPU must never be replaced or forked), and leave with its status
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import subprocess
+        cmd = launcher_command([a for a in sys.argv[1:] if a != "--dry-launch"], args.gpus)
+        if args.dry_launch:
+            print(json.dumps({"launch": cmd}))
+            sys.exit(0)
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
+    if args.dry_launch:
+        print(json.dumps({"launch": None}))
+        sys.exit(0)
 
     import torch
     import torch.distributed as dist
@@ -114,9 +186,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            print("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus, file=sys.stderr)
-            sys.exit(2)
+        print("bench.py --gpus %d inside a launcher of WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     # RC_REHEARSE_GLOO=1: rehearsal of the N>1 path on a one-GPU box (every rank on cuda:0, gloo
     # transport); never set by the driver
     rehearse = os.environ.get("RC_REHEARSE_GLOO") == "1"
@@ -314,40 +385,54 @@ def main():
     events = not args.no_kernel_events
     if events:
         ctx.profile_reset()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        # HIP events on the kernels' own stream, inside the timed region; sampled steps only,
-        # because an event pair between two kernels keeps them from overlapping at all
-        if events:
-            ctx.profile_enable(i % args.event_every == 0)
-        step()
-    finish_pending()
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if multi:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    # The timed window -- EXACTLY --steps steps between barrier + synchronize on both sides, MAX over ranks -- repeated
+    # --repeats times back to back: the headline is the median window, so it rests on R x K steps of GPU time instead of K
+    windows = []
+    gstep = 0
+    for rep in range(args.repeats):
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            # HIP events on the kernels' own stream, inside the timed region; sampled steps only,
+            # because an event pair between two kernels keeps them from overlapping at all
+            if events:
+                ctx.profile_enable(gstep % args.event_every == 0)
+            gstep += 1
+            step()
+        finish_pending()
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if multi:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        windows.append(el)
+    elapsed = float(np.median(windows))
+    sampled_steps = len(range(0, gstep, args.event_every))
     prof = []
     if events:
         ctx.profile_enable(False)
         prof = ctx.profile_read()
+    # evidence that N ranks sat on N devices: every rank's device uuid / PCI location, gathered
+    ident = device_identity(torch, dev)
+    ident.update(rank=rank, local_rank=local_rank, host=os.uname().nodename)
+    idents = [ident]
+    if multi:
+        idents = [None] * dist.get_world_size()
+        dist.all_gather_object(idents, ident)
     roof = None
-    if rank == 0 and not args.no_roof:
-        try:
-            roof = ctx.measure_memory_roof(1 << 30)
-        except Exception:
-            roof = None
+    if rank == 0 and world == 1 and not args.no_roof:
+        roof = measured_memory_roof()
 
     if rank == 0:
         frames_done = world * args.pairs * args.steps
         fps = frames_done / elapsed
+        distinct = len({(d.get("host"), d.get("uuid") or d.get("pci") or d.get("index")) for d in idents})
         model_b = survey_model_bytes_per_frame(W, H, params["levels"], params["iterations"])
         mode_names = {"clip": "", "frame": " [one resident frame per call]", "host": " [host frames, PCIe upload inclusive, flow resident]",
                       "host-stateless": " [two-image host-pointer drop-in, PCIe both ways, blocking]"}
@@ -360,6 +445,9 @@ def main():
             "headline": args.mode == "clip" and args.config == "c2" and not args.exact and not args.gaussian,
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "repeats": args.repeats, "value_min": round(frames_done / max(windows), 2), "value_max": round(frames_done / min(windows), 2),
+            "timed_seconds_total": round(sum(windows), 4),
+            "ranks": dist.get_world_size() if multi else 1, "distinct_devices": distinct, "devices": idents,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "%s %dx%d synthetic %s clip, %d pyramid scales (levels=%d), winsize 3, iters 2, poly_n 15, sigma 1.2, "
@@ -395,11 +483,13 @@ def main():
                                "traffic": traffic, "traffic_source": src,
                                "avg_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
                                "alg_bytes_per_launch": dom["alg_bytes"] / dom["launches"],
+                               "alg_bytes_per_px_pair": round(dom["alg_bytes"] / dom["launches"] / (W * H * min(args.pairs, args.chunk or 32)), 3),
                                "alg_bytes_def": ("bytes of the launches of this kind as staged through HBM (exact path: M, the "
                                                  "column sums and the flow between its kernels)" if args.exact else
-                                                 "compulsory bytes of the launch as built: R0 20 + R1 20 + coarse flow 2 + "
-                                                 "flow out 8 = 50 B per pixel x 2 073 600 px x pairs per launch "
-                                                 "(M never exists in HBM, two iterations per launch)"),
+                                                 "compulsory bytes of the launch as built, per pixel of the scale and pair: R1 20 "
+                                                 "+ R0 20 x (pairs that read it from memory: the head of every tile chain; the "
+                                                 "others take it from the previous pair's R1 window in LDS) + coarse flow 2 + "
+                                                 "flow out 8 (M never exists in HBM, two iterations per launch)"),
                                "frac_of_traffic": round(traffic / secs * dom["launches"] / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                                "survey_model_equivalent": {"bytes_per_launch": dom["model_bytes"] / dom["launches"],
                                                            "GBs": round(dom["model_bytes"] / secs / 1e9, 1),
@@ -407,7 +497,7 @@ def main():
                                                                    "exceeds the peak because those bytes are never moved"},
                                "share_of_gpu_time": round(dom["total_ms"] / tot, 3)}
             # whole step: compulsory bytes of every launch of a sampled step / wall time of a step
-            step_bytes = sum(p["alg_bytes"] for p in prof) / len(range(0, args.steps, args.event_every))
+            step_bytes = sum(p["alg_bytes"] for p in prof) / sampled_steps
             out["pipeline"] = {"compulsory_bytes_per_step": step_bytes,
                                "frac": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                                "measured_bytes_per_field": pipe_bytes,
@@ -415,9 +505,8 @@ def main():
                                "note": "whole step (expansions + flow + histogram) against 8 TB/s: compulsory bytes as "
                                        "built, and FETCH/WRITE_SIZE bytes from the committed --pmc passes"}
             if roof:
-                # also against the roof this device actually reaches (streaming kernels, 1 GiB)
-                out["roofline"]["peak_measured"] = {k: round(v, 1) for k, v in roof.items()}
-                out["roofline"]["frac_of_measured_read"] = round(own / roof["read"], 4)
+                # the rates this device streams at (scripts/diag/membw), reported next to the 8 TB/s spec
+                out["roofline"]["peak_measured"] = roof
             out["kernels"] = [{"kernel": p["kernel"], "launches": p["launches"],
                                "avg_us": round(1e3 * p["total_ms"] / p["launches"], 2),
                                "GBs_compulsory": round(p["alg_bytes"] / (p["total_ms"] * 1e-3) / 1e9, 1),

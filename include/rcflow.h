@@ -91,7 +91,10 @@ int rcflow_use_own_stream(rc_ctx* ctx, int stream);
  * "exact_taps" = 1 keeps every polynomial-expansion tap instead of dropping taps whose
  * total weight is below 1e-8 of the kernel mass (default 0);
  * "fuse_iters" = 0 runs every Farneback iteration as its own launch instead of two per
- * launch (default 1; results are bit-identical either way).
+ * launch (default 1; results are bit-identical either way);
+ * "chain" = consecutive frame pairs a block of the fused winsize-3 flow kernel walks on its tile, taking pair
+ * z + 1's previous-frame coefficients out of pair z's next-frame window in LDS (the reference's u_f1.copyTo(u_f2),
+ * ripcurrents.cpp:194-221, at tile level; default 8, 1 = off; shortened automatically for small launches; same bits).
  * Measurement switches, all speed-only except where noted: "xcd_remap" (1) XCD-aware tile order;
  * "poly_tile_h" (32 | 48) rows per expansion block -- changes the per-tile DC and with it the last
  * bits of R; "poly_mfma" (0) vertical pass of the expansion on the matrix cores -- different
@@ -341,8 +344,14 @@ int rcflow_comm_rank(rc_ctx* ctx, int* rank, int* world);
 /* Starts the sum over all ranks of the slot's histogram counters as they are at this point of the slot's
  * stream; the result goes to d_words_out (device, RC_HIST_WORDS int32) or, when NULL, to a context-owned
  * buffer (rcflow_allreduce_hist_result).  Asynchronous and off the slot's stream: the collective runs on its
- * own HIP stream beside whatever the slot does next.  RC_ESTATE if the sum could exceed int32. */
+ * own HIP stream beside whatever the slot does next.  Collective: every rank calls it the same number of times,
+ * and no rank ever skips the reduction on a local condition (a rank that did would leave the others waiting). */
 int rcflow_allreduce_hist(rc_ctx* ctx, int stream, int32_t* d_words_out);
+/* Verdict on the collective started last, the same on every rank (it comes from a reduced word): waits for the
+ * collective on the host, then RC_ESTATE when the ranks together counted more pixels than the int32 histsum of the
+ * reference (ripcurrents.cpp:147-150) can hold -- reduce per shorter segment -- else RC_OK.  pixels_counted (may be
+ * NULL): the upper bound used. */
+int rcflow_allreduce_hist_status(rc_ctx* ctx, long long* pixels_counted);
 /* Orders the slot's stream after the collective started last (no host wait): call it before
  * rcflow_thresholds_words_dev(ctx, stream, d_words_out). */
 int rcflow_allreduce_hist_join(rc_ctx* ctx, int stream);
@@ -367,12 +376,6 @@ int rcflow_profile_read(rc_ctx* ctx, int cap, const char** names, int* launches,
  * names / ms: RC_PROFILE_BUCKETS entries each (either may be NULL).  Returns RC_PROFILE_BUCKETS. */
 #define RC_PROFILE_BUCKETS 7
 int rcflow_profile_read_buckets(rc_ctx* ctx, const char** names, double* ms);
-
-/* The memory roof this device actually reaches: streaming read, fill and copy
- * (read + write bytes) in GB/s over scratch buffers of `bytes` (use >= 1 GiB: beyond the Infinity
- * Cache).  Blocks; allocates and frees 2 x bytes. */
-int rcflow_measure_memory_roof(rc_ctx* ctx, int stream, size_t bytes, double* read_GBs, double* write_GBs,
-                               double* copy_GBs);
 
 #ifdef __cplusplus
 }

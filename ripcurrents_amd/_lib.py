@@ -96,13 +96,13 @@ SIGNATURES = {
     "rcflow_pyrlk_dev": [_vp, _i, _vp, _sz, _vp, _sz, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _d],
     "rcflow_pyrlk_u8": [_vp, _i, _vp, _sz, _vp, _sz, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _d],
     "rcflow_pyrlk_levels": [_i, _i, _i, _i, _i],
-    "rcflow_measure_memory_roof": [_vp, _i, _sz, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)],
     "rcflow_comm_unique_id": [_vp],
     "rcflow_comm_init": [_vp, _vp, _i, _i],
     "rcflow_comm_destroy": [_vp],
     "rcflow_comm_rank": [_vp, C.POINTER(_i), C.POINTER(_i)],
     "rcflow_allreduce_hist": [_vp, _i, _vp],
     "rcflow_allreduce_hist_join": [_vp, _i],
+    "rcflow_allreduce_hist_status": [_vp, C.POINTER(C.c_longlong)],
     "rcflow_allreduce_hist_result": [_vp, C.POINTER(_vp)],
     "rcflow_profile_enable": [_vp, _i],
     "rcflow_profile_reset": [_vp],

@@ -189,7 +189,9 @@ class Context:
 
     def frame_buffer(self, w, h, stream=0):
         """The next page-locked staging buffer of the slot as a numpy HxW uint8 view (rcflow_frame_buffer_acquire): produce
-        the frame into it, then push_frame_acquired() -- the frame loop without the staging copy."""
+        the frame into it, then push_frame_acquired() -- the frame loop without the staging copy.  The view is valid until
+        that push; a later acquire with a LARGER frame reallocates the slot's staging memory, so never keep a view across
+        a size change (take a new one per frame, as the loop does anyway)."""
         ptr, step = C.c_void_p(), C.c_size_t()
         check(self._lib.rcflow_frame_buffer_acquire(self._h, stream, w, h, C.byref(ptr), C.byref(step)))
         buf = (C.c_uint8 * (h * step.value)).from_address(ptr.value)
@@ -414,6 +416,14 @@ class Context:
     def allreduce_hist_join(self, stream=0):
         self._bind(stream)
         check(self._lib.rcflow_allreduce_hist_join(self._h, stream))
+
+    def allreduce_hist_status(self):
+        """Host wait for the collective started last, then the verdict every rank shares (rcflow_allreduce_hist_status):
+        raises RcflowError(RC_ESTATE) when the ranks together counted more pixels than an int32 histsum holds; returns the
+        upper bound of the pixels counted otherwise."""
+        n = C.c_longlong(0)
+        check(self._lib.rcflow_allreduce_hist_status(self._h, C.byref(n)))
+        return n.value
 
     def create_flow_accumulate(self, current, framecount, MID=0.5, LOWER=0.2, want=("polar", "waterclass",
                                "out", "outmask"), stream=0):
@@ -652,13 +662,6 @@ class Context:
         return check(self._lib.rcflow_pyrlk_levels(w, h, int(win[0]), int(win[1]), int(max_level)))
 
     # ------------------------------------------------------------------ measurement
-    def measure_memory_roof(self, nbytes=1 << 30, stream=0):
-        """Streaming read / fill / copy GB/s this device reaches (SURVEY 8(d) measured peak)."""
-        r, w, c = C.c_double(0), C.c_double(0), C.c_double(0)
-        self._bind(stream)
-        check(self._lib.rcflow_measure_memory_roof(self._h, stream, nbytes, C.byref(r), C.byref(w), C.byref(c)))
-        return {"read": r.value, "write": w.value, "copy": c.value}
-
     def profile_enable(self, on=True):
         check(self._lib.rcflow_profile_enable(self._h, 1 if on else 0))
 

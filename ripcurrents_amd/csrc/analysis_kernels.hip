@@ -1422,64 +1422,6 @@ extern "C" int rcflow_analysis_size(rc_ctx* ctx, int stream, int* w, int* h) {
     return RC_OK;
 }
 
-// ===================================================================== measured memory roof
-// "the build records the peak it measures with a device-copy/triad microbench and
-// reports against both".  Streaming read (float4 loads, 8192 blocks), fill and copy over a scratch
-// buffer well beyond the 256 MB Infinity Cache; HIP events on the slot's stream.
-__global__ __launch_bounds__(RC_BLOCK) void k_bw_read(const float4* __restrict__ p, size_t n4, float* out) {
-    const size_t stride = (size_t)gridDim.x * RC_BLOCK;
-    float acc = 0.f;
-    for (size_t i = (size_t)blockIdx.x * RC_BLOCK + threadIdx.x; i < n4; i += stride) {
-        float4 v = p[i];
-        acc += v.x + v.y + v.z + v.w;
-    }
-    if (acc == 12345.678f) out[0] = acc;
-}
-__global__ __launch_bounds__(RC_BLOCK) void k_bw_fill(float4* __restrict__ p, size_t n4) {
-    const size_t stride = (size_t)gridDim.x * RC_BLOCK;
-    for (size_t i = (size_t)blockIdx.x * RC_BLOCK + threadIdx.x; i < n4; i += stride) p[i] = make_float4(1.f, 2.f, 3.f, 4.f);
-}
-__global__ __launch_bounds__(RC_BLOCK) void k_bw_copy(const float4* __restrict__ s, float4* __restrict__ d, size_t n4) {
-    const size_t stride = (size_t)gridDim.x * RC_BLOCK;
-    for (size_t i = (size_t)blockIdx.x * RC_BLOCK + threadIdx.x; i < n4; i += stride) d[i] = s[i];
-}
-
-extern "C" int rcflow_measure_memory_roof(rc_ctx* ctx, int stream, size_t bytes, double* read_GBs, double* write_GBs,
-                                          double* copy_GBs) {
-    RcSlot* s = rc_slot(ctx, stream);
-    if (!s || bytes < (1u << 20)) return RC_EINVAL;
-    RC_HIP(hipSetDevice(ctx->device));
-    void *a = nullptr, *b = nullptr;
-    if (hipMalloc(&a, bytes) != hipSuccess) return RC_ENOMEM;
-    if (hipMalloc(&b, bytes + 16) != hipSuccess) { (void)hipFree(a); return RC_ENOMEM; }
-    const size_t n4 = bytes / 16;
-    hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    double out[3] = {0, 0, 0};
-    (void)hipMemsetAsync(a, 1, bytes, s->cur);
-    for (int mode = 0; mode < 3; mode++) {
-        const int reps = 6;
-        for (int r = -2; r < reps; r++) {        // two untimed passes first
-            if (r == 0) (void)hipEventRecord(e0, s->cur);
-            if (mode == 0) hipLaunchKernelGGL(k_bw_read, dim3(8192), dim3(RC_BLOCK), 0, s->cur, (const float4*)a, n4, (float*)((char*)b + bytes));
-            else if (mode == 1) hipLaunchKernelGGL(k_bw_fill, dim3(8192), dim3(RC_BLOCK), 0, s->cur, (float4*)b, n4);
-            else hipLaunchKernelGGL(k_bw_copy, dim3(8192), dim3(RC_BLOCK), 0, s->cur, (const float4*)a, (float4*)b, n4);
-        }
-        (void)hipEventRecord(e1, s->cur);
-        (void)hipEventSynchronize(e1);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        out[mode] = (mode == 2 ? 2.0 : 1.0) * (double)bytes * reps / (ms * 1e-3) / 1e9;
-    }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipFree(a); (void)hipFree(b);
-    if (read_GBs) *read_GBs = out[0];
-    if (write_GBs) *write_GBs = out[1];
-    if (copy_GBs) *copy_GBs = out[2];
-    RC_HIP(hipGetLastError());
-    return RC_OK;
-}
-
 // ===================================================================== INTER_AREA pre-processing
 // resize(frame, Size(dw, dh), 0, 0, INTER_AREA) + cvtColor(BGR2GRAY) for the first frame of a run
 // (ripcurrents.cpp:186, main.cpp:126, ...).  resize.cpp: integer factors -> resizeAreaFast_ (sum of the

@@ -18,16 +18,21 @@
 
 #include "rc_host.h"
 
+#define RC_COUNT_UNIT 2048ll
+#define RC_COMM_WORDS (RC_HIST_WORDS + 1)
+
 struct RcComm {
     int rank = 0, world = 1;
     void* lib = nullptr;
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ready = nullptr, done = nullptr;
+    // RC_HIST_WORDS counters + one word every rank fills with the pixels it has counted, in units of RC_COUNT_UNIT,
+    // rounded up: the reduced word bounds the summed histsum on every rank alike (rcflow_allreduce_hist_status)
     int32_t* staging = nullptr;       // the rank's counters as sent
-    int32_t* result = nullptr;        // context-owned output when the caller passes none
+    int32_t* reduced = nullptr;       // the reduced words + the count word, as the collective leaves them
+    int32_t* result = nullptr;        // context-owned output when the caller passes none (RC_HIST_WORDS)
     int pending = 0;
-    long long hist_added_sent = 0;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -68,6 +73,7 @@ extern "C" int rcflow_comm_destroy(rc_ctx* ctx) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->staging) (void)hipFree(c->staging);
     if (c->result) (void)hipFree(c->result);
+    if (c->reduced) (void)hipFree(c->reduced);
     delete c;
     ctx->comm = nullptr;
     return RC_OK;
@@ -87,7 +93,8 @@ extern "C" int rcflow_comm_init(rc_ctx* ctx, const void* unique_id, int rank, in
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess ||
-        hipMalloc(&c->staging, RC_HIST_WORDS * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc(&c->staging, RC_COMM_WORDS * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc(&c->reduced, RC_COMM_WORDS * sizeof(int32_t)) != hipSuccess ||
         hipMalloc(&c->result, RC_HIST_WORDS * sizeof(int32_t)) != hipSuccess) {
         rc_set_error("rcflow_comm_init: stream / event / buffer creation failed");
         return fail(RC_EHIP);
@@ -124,29 +131,28 @@ extern "C" int rcflow_allreduce_hist(rc_ctx* ctx, int stream, int32_t* d_words_o
     RcComm* c = (RcComm*)ctx->comm;
     if (!c) { rc_set_error("collective layer not initialised (rcflow_comm_init)"); return RC_ECOMM; }
     if (!s->an.hist.p) { rc_set_error("no histogram state: call rcflow_analysis_reset first"); return RC_ESTATE; }
-    // the summed histsum must fit the int32 payload: every rank's counters are bounded by the pixels it counted
-    if (s->an.hist_added * c->world > 0x7fffffffll) {
-        rc_set_error("the %d-rank sum of the flow histogram could exceed int32 (%lld pixels counted on this rank): "
-                     "all-reduce per shorter segment (rcflow_histogram_reset_dev)", c->world, s->an.hist_added);
-        return RC_ESTATE;
-    }
+    // No rank may decide on its own to skip the collective (the others would wait in it for ever): whether the summed
+    // histsum fits the int32 payload is decided AFTER the reduction, from a reduced word that is the same on every
+    // rank (rcflow_allreduce_hist_status).  Every rank must call this function the same number of times.
     RC_HIP(hipSetDevice(ctx->device));
-    int32_t* out = d_words_out ? d_words_out : c->result;
     // snapshot of the counters in the slot's stream order; the collective stream picks it up from there.
     // (a collective still in flight reads the previous snapshot: order the copy after it)
     if (c->pending) RC_HIP(hipStreamWaitEvent(s->cur, c->done, 0));
     RC_HIP(hipMemcpyAsync(c->staging, s->an.hist.p, RC_HIST_WORDS * sizeof(int32_t), hipMemcpyDeviceToDevice, s->cur));
+    const int units = (int)((s->an.hist_added + RC_COUNT_UNIT - 1) / RC_COUNT_UNIT);       // <= 2^20 (hist_added <= INT32_MAX)
+    RC_HIP(hipMemsetD32Async((hipDeviceptr_t)(c->staging + RC_HIST_WORDS), units, 1, s->cur));
     RC_HIP(hipEventRecord(c->ready, s->cur));
     RC_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
     if (!c->comm) {                                     // world of one without RCCL
-        RC_HIP(hipMemcpyAsync(out, c->staging, RC_HIST_WORDS * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+        RC_HIP(hipMemcpyAsync(c->reduced, c->staging, RC_COMM_WORDS * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
     } else {
-        ncclResult_t r = c->AllReduce(c->staging, out, RC_HIST_WORDS, ncclInt32, ncclSum, c->comm, c->stream);
+        ncclResult_t r = c->AllReduce(c->staging, c->reduced, RC_COMM_WORDS, ncclInt32, ncclSum, c->comm, c->stream);
         if (r != ncclSuccess) {
             rc_set_error("ncclAllReduce failed: %s", c->GetErrorString ? c->GetErrorString(r) : "?");
             return RC_ECOMM;
         }
     }
+    RC_HIP(hipMemcpyAsync(d_words_out ? d_words_out : c->result, c->reduced, RC_HIST_WORDS * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
     RC_HIP(hipEventRecord(c->done, c->stream));
     c->pending = 1;
     return RC_OK;
@@ -160,6 +166,29 @@ extern "C" int rcflow_allreduce_hist_join(rc_ctx* ctx, int stream) {
     if (!c->pending) return RC_OK;
     RC_HIP(hipSetDevice(ctx->device));
     RC_HIP(hipStreamWaitEvent(s->cur, c->done, 0));
+    return RC_OK;
+}
+
+// The verdict on the collective started last, identical on every rank because it is computed from a reduced word:
+// waits for the collective (host wait), then RC_ESTATE when the ranks together counted more pixels than an int32
+// histsum can hold (an upper bound: every rank rounds its count up to RC_COUNT_UNIT), RC_OK otherwise.
+extern "C" int rcflow_allreduce_hist_status(rc_ctx* ctx, long long* pixels_counted) {
+    if (!ctx) return RC_EINVAL;
+    RcComm* c = (RcComm*)ctx->comm;
+    if (!c) { rc_set_error("collective layer not initialised (rcflow_comm_init)"); return RC_ECOMM; }
+    if (pixels_counted) *pixels_counted = 0;
+    if (!c->pending) return RC_OK;
+    RC_HIP(hipSetDevice(ctx->device));
+    RC_HIP(hipEventSynchronize(c->done));
+    int32_t units = 0;
+    RC_HIP(hipMemcpy(&units, c->reduced + RC_HIST_WORDS, sizeof(units), hipMemcpyDeviceToHost));
+    const long long px = (long long)units * RC_COUNT_UNIT;
+    if (pixels_counted) *pixels_counted = px;
+    if (px > 0x7fffffffll) {
+        rc_set_error("the %d ranks counted up to %lld pixels: the summed flow histogram may have wrapped int32 -- "
+                     "all-reduce per shorter segment (rcflow_histogram_reset_dev)", c->world, px);
+        return RC_ESTATE;
+    }
     return RC_OK;
 }
 

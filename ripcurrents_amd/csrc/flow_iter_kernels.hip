@@ -2202,6 +2202,15 @@ static void launch_w3x2(RcIterArgs a, int pairs, hipStream_t s) {
 
 int rc_flow_iter_can_fuse2(const RcIterArgs& a) { return a.win.m == 1 && a.solve; }
 
+// How many of the launch's `pairs` read their previous-frame coefficients R0 from memory (the head of every tile
+// chain; the others take them from the previous pair's LDS window): the compulsory bytes of the launch as built.
+int rc_flow_iter2_r0_reads(const RcIterArgs& a, int pairs) {
+    if (a.ablate & (RC_ABL_W3X2_LDS_M | RC_ABL_RR_28X20 | RC_ABL_RR_28X12 | RC_ABL_RR_60X28 | RC_ABL_RR_DB | RC_ABL_RR_512T | RC_ABL_RR_512T_8W)) return pairs;
+    RcChainPlan cp;
+    rc_chain_plan(a, pairs, (long long)((a.w + 27) / 28) * ((a.h + 27) / 28), cp);
+    return cp.ngroups ? cp.ngroups : pairs;
+}
+
 void rc_launch_flow_iter2(const RcIterArgs& a, int pairs, hipStream_t s) {
     const int g = a.win.gaussian ? 1 : 0;
     switch (a.in_mode * 2 + g) {

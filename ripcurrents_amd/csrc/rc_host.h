@@ -53,6 +53,11 @@ struct RcSlot {
     int fev_i = 0;
     hipEvent_t flow_done[2] = {nullptr, nullptr};   // the flow launches of the last two pushes
     int flow_done_i = 0;
+    // consecutive two-stream pushes so far: the second stream may run ahead of the slot's stream only past work those
+    // pushes recorded themselves; anything else queued on the slot (a clip, a pair call, priming, the one-stream path)
+    // zeroes the streak (expand_frames / compute_flows) and the next two-stream push first joins the slot's stream
+    int ts_streak = 0;
+    bool in_ts_push = false;
     RcPlan plan;
     RcBuf kern;
     RcBuf I[RC_MAX_LEVELS], RA[RC_MAX_LEVELS], RB[RC_MAX_LEVELS];

@@ -592,6 +592,7 @@ static int ensure_plan(rc_ctx* ctx, RcSlot& s, int w, int h, const rc_farneback_
 // Pyramid + polynomial expansion of `count` frames into R slots dslot0.. (A1 + A2).
 static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t frame_stride, size_t step,
                          int count, int dslot0, int zstep = 1) {
+    if (!s.in_ts_push) s.ts_streak = 0;      // work on the slot outside a two-stream frame push (see RcSlot::ts_streak)
     RcPlan& pl = s.plan;
     RcPolyArgs qa[RC_MAX_LEVELS];
     RcPyrArgs pa[RC_MAX_LEVELS];
@@ -747,6 +748,7 @@ static int compute_flows_exact(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, flo
 // Coarse-to-fine flow for `pairs` frame pairs whose expansions sit in slots slot0+z, slot0+z+1.
 static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_out, size_t out_pair_stride,
                          size_t out_step, int slot1 = -1, int zstep = 1) {
+    if (!s.in_ts_push) s.ts_streak = 0;
     // option "exact": box windows replay upstream's running sums (exact_kernels.hip); Gaussian windows run the
     // kernels below from the build of flow_iter_kernels.hip that keeps upstream's operation order
     if (s.plan.exact && !s.plan.win.gaussian)
@@ -808,8 +810,11 @@ static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_
                 double model = 0;
                 if (i == 0) model += 60. * n + (coarse ? 8. * cw * ch : 0.);
                 for (int j = i; j < i + fuse; j++) model += (j == passes - 1) ? 28. * n : 80. * n;
+                // compulsory bytes as built: R1 20 B/px per pair, R0 20 B/px per pair that reads it from memory (the head of
+                // a tile chain; the rest take it from the previous pair's LDS window), flow in, flow out
+                const int r0 = fuse != 2 ? pairs : exact ? rc_flow_exact::rc_flow_iter2_r0_reads(a, pairs) : rc_flow_fast::rc_flow_iter2_r0_reads(a, pairs);
                 RcProfScope ps(ctx, s.cur, fuse == 2 ? RC_K_ITER2 : RC_K_ITER, k,
-                               (double)pairs * ((a.solve ? 40. : 0.) * n + in_bytes + 8. * n), (double)pairs * model);
+                               (a.solve ? 20. * n * (pairs + r0) : 0.) + (double)pairs * (in_bytes + 8. * n), (double)pairs * model);
                 if (exact) {
                     if (fuse == 2) rc_flow_exact::rc_launch_flow_iter2(a, pairs, s.cur);
                     else rc_flow_exact::rc_launch_flow_iter(a, pairs, s.cur);
@@ -842,6 +847,7 @@ extern "C" int rcflow_farneback_dev(rc_ctx* ctx, int stream, const uint8_t* d_pr
     if (rc) return rc;
     s->primed = 0;
     s->batch_primed = 0;
+    s->flow_w = s->flow_h = 0;      // the stream starts over: no resident flow field of its own (rcflow_stream_flow_ptr)
     if ((rc = expand_frames(ctx, *s, d_prev, 0, prev_step, 1, 0))) return rc;
     if ((rc = expand_frames(ctx, *s, d_next, 0, next_step, 1, 1))) return rc;
     return compute_flows(ctx, *s, 1, 0, d_flow, 0, flow_step);
@@ -924,22 +930,38 @@ static int push_frame_core(rc_ctx* ctx, RcSlot* s, int stream, const uint8_t* d_
     if (two_streams && !ctx->prof_on && s->plan.nslots >= 4) {
         if (!s->aux) RC_HIP(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
         for (auto& e : s->flow_done) if (!e) { RC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); RC_HIP(hipEventRecord(e, s->cur)); }
+        hipStream_t main_stream = s->cur;
+        const int older = s->flow_done_i;                  // written two pushes ago
+        if (s->ts_streak == 0) {
+            // The previous operation on the slot was not a two-stream push (priming, a clip or pair call, the
+            // one-stream path, a reset): its kernels may still read the ring slot, the scale images and the frame
+            // buffers this push is about to overwrite, and no flow_done event covers them.  Join the slot's stream
+            // once; from the next push on the flow_done events carry the order.
+            hipEvent_t& joined = s->fev[s->fev_i];
+            s->fev_i = (s->fev_i + 1) % 8;
+            if (!joined) RC_HIP(hipEventCreateWithFlags(&joined, hipEventDisableTiming));
+            RC_HIP(hipEventRecord(joined, main_stream));
+            RC_HIP(hipStreamWaitEvent(s->aux, joined, 0));
+        } else {
+            RC_HIP(hipStreamWaitEvent(s->aux, s->flow_done[older], 0));
+        }
         hipEvent_t& expanded = s->fev[s->fev_i];
         s->fev_i = (s->fev_i + 1) % 8;
         if (!expanded) RC_HIP(hipEventCreateWithFlags(&expanded, hipEventDisableTiming));
-        hipStream_t main_stream = s->cur;
-        const int older = s->flow_done_i;                  // written two pushes ago
-        RC_HIP(hipStreamWaitEvent(s->aux, s->flow_done[older], 0));
         if ((rc = upload_on(s->aux))) return rc;
+        s->in_ts_push = true;
         s->cur = s->aux;
         rc = expand_frames(ctx, *s, d_frame, 0, step, 1, nxt);
         s->cur = main_stream;
-        if (rc) return rc;
+        if (rc) { s->in_ts_push = false; return rc; }
         RC_HIP(hipEventRecord(expanded, s->aux));
         RC_HIP(hipStreamWaitEvent(main_stream, expanded, 0));
-        if ((rc = compute_flows(ctx, *s, 1, s->cur_slot, d_flow, 0, flow_step))) return rc;
+        rc = compute_flows(ctx, *s, 1, s->cur_slot, d_flow, 0, flow_step);
+        s->in_ts_push = false;
+        if (rc) return rc;
         RC_HIP(hipEventRecord(s->flow_done[older], main_stream));
         s->flow_done_i = older ^ 1;
+        s->ts_streak++;
         s->cur_slot = nxt;
         return RC_OK;
     }

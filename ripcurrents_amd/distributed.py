@@ -78,7 +78,9 @@ def init_comm(ctx, group=None, rccl_for_one=False):
         return 0, 1
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     box = [ctx.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0, group=group)
+    # `rank` is the rank inside `group`; broadcast's src is a GLOBAL rank: the group's first member, not always 0
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast_object_list(box, src=src, group=group)
     ctx.comm_init(rank, world, box[0])
     return rank, world
 

@@ -123,3 +123,28 @@ def test_every_option_is_documented_in_the_header():
     assert len(names) >= 10
     missing = [n for n in sorted(names) if '"%s"' % n not in hdr]
     assert not missing, missing
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` without a launcher around it starts one itself (a child process, before any GPU call):
+    the same torch.distributed.run line the driver uses, rendezvous on 127.0.0.1, the script's own arguments passed on.
+    --dry-launch prints the command instead of running it (no GPU, no torch import)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5",
+                          "--dry-launch"], capture_output=True, text=True, timeout=60, env=env)
+    assert out.returncode == 0, out.stderr
+    cmd = json.loads(out.stdout)["launch"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 1024
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    # one GPU, or a launcher already around the script: nothing to start
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-launch"], capture_output=True,
+                         text=True, timeout=60, env=env)
+    assert json.loads(out.stdout)["launch"] is None
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-launch"], capture_output=True,
+                         text=True, timeout=60, env=dict(env, WORLD_SIZE="8", RANK="0", LOCAL_RANK="0"))
+    assert json.loads(out.stdout)["launch"] is None

@@ -748,6 +748,45 @@ def test_frame_loop_on_two_streams_same_bits(ctx):
     ctx.stream_reset()
 
 
+def test_two_stream_pushes_after_clip_and_pair_calls_same_bits(ctx):
+    """The entry points interoperate on one slot (include/rcflow.h): two-stream frame pushes, then a clip push that reads
+    every ring slot for a whole chunk, then two-stream pushes again, a pair call and a reset in between -- no host
+    synchronisation anywhere.  The second stream of a frame push may only run ahead of work that earlier two-stream
+    pushes recorded; after anything else it first joins the slot's stream (RcSlot::ts_streak).  Same flow fields as the
+    synchronised clip call."""
+    w, h, T = 640, 480, 22
+    p = dict(pyr_scale=0.5, levels=2, winsize=3, iterations=2, poly_n=15, poly_sigma=1.2, flags=0)
+    d = torch.as_tensor(synth.surf_clip(w, h, T, seed=33)).cuda()
+    ref = ctx.farneback_clip(d, **p).clone()
+    torch.cuda.synchronize()
+    ctx.set_option("chunk", 6)                       # ring of 7 slots: the clip push below wraps it
+    ctx.set_option("frame_overlap", 2)
+    try:
+        for rep in range(3):
+            ctx.stream_reset()
+            outs = torch.zeros((T - 1, h, w, 2), dtype=torch.float32, device="cuda")
+            assert ctx.push_frame(d[0], **p) is None
+            for t in (1, 2, 3):                          # two-stream pushes
+                ctx.push_frame(d[t], outs[t - 1], **p)
+            got = ctx.push_clip(d[4:13], outs[3:12], **p)    # a clip of more than a chunk on the slot's stream
+            assert got.shape[0] == 9
+            for t in (13, 14, 15):                       # straight back to two-stream pushes
+                ctx.push_frame(d[t], outs[t - 1], **p)
+            pair = torch.zeros((h, w, 2), dtype=torch.float32, device="cuda")
+            ctx.calcOpticalFlowFarneback(d[5], d[6], pair, **p)      # asynchronous pair call: restarts the stream
+            assert ctx.push_frame(d[15], **p) is None
+            for t in range(16, T):
+                ctx.push_frame(d[t], outs[t - 1], **p)
+            ctx.sync()
+            torch.cuda.synchronize()
+            assert torch.equal(outs, ref), "repetition %d" % rep
+            assert torch.equal(pair, ref[5])
+    finally:
+        ctx.set_option("frame_overlap", 1)
+        ctx.set_option("chunk", 32)
+        ctx.stream_reset()
+
+
 def test_host_frame_loop_argument_and_state_errors(ctx):
     """Error behaviour of the host-frame entry points: bad arguments, oversize frames, reading a flow that does not
     exist yet, a size change in mid-stream (re-primes, like the device-pointer loop)."""
@@ -775,7 +814,10 @@ def test_host_frame_loop_argument_and_state_errors(ctx):
     with pytest.raises(RcflowError):
         ctx.stream_flow_read(96, 80)
     f = ctx.push_frame_host(small[1], **pk)
-    ref = ctx.calcOpticalFlowFarneback(small[0], small[1], None, **pk)
     ctx.sync()
-    assert np.array_equal(f.cpu().numpy(), ref)
+    got = f.cpu().numpy().copy()          # `f` aliases the slot's staging field, which the host-pointer pair call below reuses
+    ref = ctx.calcOpticalFlowFarneback(small[0], small[1], None, **pk)
+    assert np.array_equal(got, ref)
+    with pytest.raises(RcflowError):      # the pair call restarted the stream: it has no flow field of its own any more
+        ctx.stream_flow_read(96, 80)
     ctx.stream_reset()

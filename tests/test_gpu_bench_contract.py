@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_prints_one_contract_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--pairs", "16",
-                          "--cpu-pairs", "1", "--warmup-seconds", "0.2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--cpu-pairs", "1", "--warmup-seconds", "0.2", "--repeats", "4"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -36,22 +36,35 @@ def test_bench_prints_one_contract_line():
     assert "traffic_source" in r and (r["traffic"] is None or r["traffic_source"])
     assert 0.0 < j["pipeline"]["frac"] < 1.0 and all(0.0 < k["frac"] < 1.0 for k in j["kernels"])
     assert j["warmup_steps_run"] >= 1
+    # the headline is the median of `repeats` timed windows of exactly `steps` steps each
+    assert j["repeats"] == 4 and j["value_min"] <= j["value"] <= j["value_max"] and j["timed_seconds_total"] > 0
+    # device evidence: one rank, one device, with something that identifies it
+    assert j["ranks"] == 1 and j["distinct_devices"] == 1 and len(j["devices"]) == 1
+    assert j["devices"][0]["rank"] == 0 and ("uuid" in j["devices"][0] or "pci" in j["devices"][0])
     c = j["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
 
 
-def test_bench_two_ranks_rehearsal():
-    """The N>1 path of bench.py end to end on the one GPU of the test box: two ranks launched the way the
-    driver launches them (torch.distributed.run), both on cuda:0 with gloo as the transport
-    (RC_REHEARSE_GLOO=1; RCCL refuses two ranks on one device).  Segments per rank, the asynchronous
-    histogram all-reduce consumed one step later, max-over-ranks timing, one JSON line from rank 0."""
+@pytest.mark.parametrize("how", ["launcher", "plain"])
+def test_bench_two_ranks_rehearsal(how):
+    """The N>1 path of bench.py end to end on the one GPU of the test box, both ways the driver may start it: under
+    torch.distributed.run, and as a plain `python bench.py --gpus 2` (no WORLD_SIZE: the script then starts the launcher
+    itself, as a child, before it touches the GPU).  Both ranks on cuda:0 with gloo as the transport (RC_REHEARSE_GLOO=1;
+    RCCL refuses two ranks on one device).  Segments per rank, the asynchronous histogram all-reduce consumed one step
+    later, max-over-ranks timing, one JSON line from rank 0 that names every rank's device."""
     env = dict(os.environ, RC_REHEARSE_GLOO="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
     port = 29600 + os.getpid() % 300
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--pairs", "4", "--no-roof", "--warmup-seconds", "0.2"]
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "4", "--no-roof",
+            "--warmup-seconds", "0.2", "--repeats", "3"]
+    if how == "launcher":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + args
+    else:
+        cmd = [sys.executable] + args
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -61,6 +74,8 @@ def test_bench_two_ranks_rehearsal():
     assert "all_reduce int32[1887]" in j["config"]["collective"]
     assert abs(j["value"] - 2 * 4 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 0.01
     assert "cpu_baseline" not in j          # rank 0 at N = 1 only
+    assert j["ranks"] == 2 and sorted(d["rank"] for d in j["devices"]) == [0, 1]
+    assert j["distinct_devices"] == 1       # the rehearsal puts both ranks on the box's one GPU; a real run reports N
 
 
 @pytest.mark.parametrize("collective", ["torch", "rccl"])

@@ -69,6 +69,9 @@ def test_one_rank_rccl_communicator_runs_the_real_collective(ctx):
             mine = ctx.histogram_words().cpu().numpy()
             assert np.array_equal(g.cpu().numpy(), mine)
             assert 0 < mine[50 + 36 * 50] <= rep * w * h          # histsum: the pixels inside the 50 magnitude bins
+            # the verdict every rank shares comes from a reduced word (pixels counted, rounded up to 2048 per rank)
+            counted = ctx.allreduce_hist_status()
+            assert rep * w * h <= counted < rep * w * h + 2048
     finally:
         ctx.comm_destroy()
 
@@ -94,6 +97,15 @@ def test_histogram_refuses_to_wrap_int32(ctx):
         ctx.histogram_accumulate_clip(flows)
     assert e.value.code == -6          # RC_ESTATE
     assert ctx.histogram_read().histsum == st.histsum                      # the refused call counted nothing
+    # the collective never skips the reduction on a local condition (a rank that did would hang the others): it runs,
+    # and the verdict comes afterwards from the reduced pixel count, the same on every rank -- here one rank just
+    # below the limit is fine
+    ctx.comm_init(0, 1)
+    try:
+        ctx.allreduce_hist()
+        assert ctx.allreduce_hist_status() >= st.histsum
+    finally:
+        ctx.comm_destroy()
     ctx.histogram_reset()
     ctx.histogram_accumulate_clip(flows[:2])
     assert ctx.histogram_read().histsum == 2 * w * h
