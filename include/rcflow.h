@@ -147,6 +147,29 @@ int rcflow_frame_buffer_acquire(rc_ctx* ctx, int stream, int w, int h, uint8_t**
 int rcflow_push_frame_acquired(rc_ctx* ctx, int stream, const rc_farneback_params* p);
 int rcflow_stream_flow_ptr(rc_ctx* ctx, int stream, float** d_flow_xy, int* w, int* h);
 int rcflow_stream_flow_read(rc_ctx* ctx, int stream, float* flow_xy, size_t flow_step);
+
+/* One whole iteration of the reference's frame loop (ripcurrents.cpp:194-479) per call, on the device (with use_graph:
+ * as ONE hipGraph launch per frame once the slot has seen the same configuration twice): the frame the host produced into the buffer of
+ * rcflow_frame_buffer_acquire is uploaded and expanded, the flow against the previous frame is computed (:215), then on
+ * that resident field: streamline_field(dt, iterations) with the PREVIOUS frame's UPPER (:229-231), the seed
+ * streamlines (:283-285, rcflow_advect_points_dev semantics; nseeds may be 0), the cumulative histogram and the
+ * thresholds (:319-366), create_flow + create_accumulationbuffer with framecount = the number of flow fields of this
+ * stream so far (:376-439; the counter lives on the device so that the captured launch sequence stays valid), and the
+ * mask's edges (:477-479; d_edges and d_outmask may be NULL).  Same kernels, same order, same bits as the separate
+ * calls.  Returns 1 when the call only primed the stream (first frame, or another size / other parameters: no flow
+ * yet), RC_ESTATE without an acquired frame buffer.  The slot keeps a ring of two expansions while it is driven this
+ * way; rcflow_stream_reset (or any other entry point on the slot) restarts it. */
+typedef struct rc_frame_loop {
+    float dt; int iterations;                 /* streamline_field */
+    float* d_seeds; int nseeds;               /* device, nseeds x (x, y), advanced in place */
+    int seed_variant; float seed_dt; int seed_iterations; float seed_upper;
+    float MID, LOWER;                         /* ripcurrents.cpp:142-143: 0.5, 0.2 */
+    uint8_t* d_outmask; size_t mask_step;     /* device 8UC1, optional */
+    uint8_t* d_edges; size_t edges_step;      /* device 8UC1, optional (needs d_outmask) */
+    int use_graph;                            /* 0 (default): the launches are issued one by one, upload and expansion on the slot's
+                                               * second stream; 1: one captured hipGraph launch per frame on a ring of two expansions */
+} rc_frame_loop;
+int rcflow_frame_loop_step(rc_ctx* ctx, int stream, const rc_farneback_params* p, const rc_frame_loop* loop);
 /* Batched form of the same stream: the nframes frames continue the slot's stream, every frame is expanded
  * once however the segment is cut into calls.  Returns the number of flow fields written to d_flows[0..):
  * nframes if the stream was primed (flow 0 = last frame of the previous call -> d_frames[0]), nframes - 1 if

@@ -407,7 +407,10 @@ void orc_vector_to_color(const float* flow, size_t flow_step, int w, int h, uint
         const float* p = row_ptr(flow, flow_step, row);
         uint8_t* q = row_ptr(hsv, hsv_step, row);
         for (int col = 0; col < w; col++) {
-            float theta = (float)(atan2f(p[1], p[0]) * 180 / M_PI);
+            // ripcurrents_module.cpp:1030: `atan2(ptr->y, ptr->x)` on floats is libm's atan2f, accurate to an ulp but not
+            // the same ulp on every platform (glibc 2.35, newer glibc, Apple's libm).  Pinned here as the correctly rounded
+            // float: the double atan2 rounded once.  Everything after it is IEEE arithmetic as written.
+            float theta = (float)((float)std::atan2((double)p[1], (double)p[0]) * 180 / M_PI);
             theta += theta < 0 ? 360 : 0;
             q[0] = f2u8(theta / 2);
             q[1] = 255;

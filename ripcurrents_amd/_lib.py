@@ -32,6 +32,14 @@ class FarnebackParams(C.Structure):
                 ("flags", C.c_int)]
 
 
+class FrameLoop(C.Structure):
+    """rc_frame_loop (include/rcflow.h): the per-frame analysis chain of rcflow_frame_loop_step."""
+    _fields_ = [("dt", C.c_float), ("iterations", C.c_int), ("d_seeds", C.c_void_p), ("nseeds", C.c_int),
+                ("seed_variant", C.c_int), ("seed_dt", C.c_float), ("seed_iterations", C.c_int), ("seed_upper", C.c_float),
+                ("MID", C.c_float), ("LOWER", C.c_float), ("d_outmask", C.c_void_p), ("mask_step", C.c_size_t),
+                ("d_edges", C.c_void_p), ("edges_step", C.c_size_t), ("use_graph", C.c_int)]
+
+
 _vp, _sz, _i, _f, _d = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double
 _pp = C.POINTER(FarnebackParams)
 
@@ -54,6 +62,7 @@ SIGNATURES = {
     "rcflow_push_frame_acquired": [_vp, _i, _pp],
     "rcflow_stream_flow_ptr": [_vp, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i)],
     "rcflow_stream_flow_read": [_vp, _i, _vp, _sz],
+    "rcflow_frame_loop_step": [_vp, _i, _pp, C.POINTER(FrameLoop)],
     "rcflow_farneback_clip_dev": [_vp, _i, _vp, _sz, _sz, _i, _i, _i, _vp, _sz, _sz, _pp],
     "rcflow_push_clip_dev": [_vp, _i, _vp, _sz, _sz, _i, _i, _i, _vp, _sz, _sz, _pp],
     "rcflow_push_batch_dev": [_vp, _i, _vp, _sz, _sz, _i, _i, _i, _vp, _sz, _sz, _pp, _i],

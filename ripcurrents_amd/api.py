@@ -209,6 +209,35 @@ class Context:
         check(self._lib.rcflow_stream_flow_ptr(self._h, stream, C.byref(d), None, None))
         return _alias_tensor(d.value, h * w * 2, torch.float32, self.device).view(h, w, 2)
 
+    def frame_loop_step(self, w, h, seeds=None, outmask=None, edges=None, dt=2.0, iterations=1, seed_dt=2.0,
+                        seed_iterations=1, seed_upper=100.0, seed_variant=3, MID=0.5, LOWER=0.2, use_graph=False,
+                        stream=0, **kw):
+        """One iteration of the reference's frame loop (ripcurrents.cpp:194-479) on the frame produced into frame_buffer():
+        flow against the previous frame, streamline_field, seed streamlines, histogram + thresholds, classify / accumulate
+        (framecount counted on the device), mask edges -- rcflow_frame_loop_step.  Returns the resident flow field, or
+        None for the call that primes the stream."""
+        from ._lib import FrameLoop
+        p = _params(kw.get("pyr_scale", 0.5), kw.get("levels", 2), kw.get("winsize", 3), kw.get("iterations_flow", 2),
+                    kw.get("poly_n", 15), kw.get("poly_sigma", 1.2), kw.get("flags", 0))
+        L = FrameLoop()
+        L.dt, L.iterations = dt, iterations
+        if seeds is not None:
+            L.d_seeds, L.nseeds = self._ptr(seeds), seeds.shape[0]
+        L.seed_variant, L.seed_dt, L.seed_iterations, L.seed_upper = seed_variant, seed_dt, seed_iterations, seed_upper
+        L.MID, L.LOWER = MID, LOWER
+        if outmask is not None:
+            L.d_outmask, L.mask_step = self._ptr(outmask), outmask.stride(0)
+        if edges is not None:
+            L.d_edges, L.edges_step = self._ptr(edges), edges.stride(0)
+        L.use_graph = 1 if use_graph else 0
+        self._bind(stream)
+        rc = check(self._lib.rcflow_frame_loop_step(self._h, stream, C.byref(p), C.byref(L)))
+        if rc == 1:
+            return None
+        d = C.c_void_p()
+        check(self._lib.rcflow_stream_flow_ptr(self._h, stream, C.byref(d), None, None))
+        return _alias_tensor(d.value, h * w * 2, torch.float32, self.device).view(h, w, 2)
+
     def stream_flow_read(self, w, h, stream=0):
         out = np.empty((h, w, 2), np.float32)
         self._bind(stream)

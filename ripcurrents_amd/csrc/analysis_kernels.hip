@@ -399,6 +399,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_thresholds(const int* words, float
 struct ClassifyArgs {
     const float* flow; size_t flow_step;
     int w, h, framecount;
+    const int* d_framecount;      // non-null: the frame counter lives on the device (rcflow_frame_loop_step)
     float MID, LOWER;
     const float* thr;
     float* acc;
@@ -413,6 +414,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_classify_accumulate(ClassifyArgs a
     if (threadIdx.x < RC_HIST_DIRECTIONS) s_u2d[threadIdx.x] = a.thr[THR_UPPER2D + threadIdx.x];
     __syncthreads();
     const float UPPER = a.thr[THR_UPPER];
+    const int framecount = a.d_framecount ? *a.d_framecount : a.framecount;
     const long long total = (long long)a.w * a.h;
     for (long long i = (long long)blockIdx.x * RC_BLOCK + threadIdx.x; i < total;
          i += (long long)gridDim.x * RC_BLOCK) {
@@ -438,15 +440,15 @@ __global__ __launch_bounds__(RC_BLOCK) void k_classify_accumulate(ClassifyArgs a
         }
         // create_accumulationbuffer: ripcurrents_module.cpp:191-211
         float acc = a.acc[i];
-        if (a.framecount > 30) {
+        if (framecount > 30) {
             acc = inc + acc;
             a.acc[i] = acc;
         }
         int v = (int)acc;
         float ox = 0.f, oy = 0.f, oz = 0.f;
         uint8_t mk = 0;
-        if (v > .1 * a.framecount) {
-            if (v < .2 * a.framecount) oz = 1.f;
+        if (v > .1 * framecount) {
+            if (v < .2 * framecount) oz = 1.f;
             else ox = 1.f;
         } else {
             oy = .5f;
@@ -651,7 +653,10 @@ __global__ __launch_bounds__(RC_BLOCK) void k_vector_to_color(const float* flow,
          i += (long long)gridDim.x * RC_BLOCK) {
         int y = (int)(i / w), x = (int)(i - (long long)y * w);
         float2 f = rc_row2(flow, step, y)[x];
-        float theta = (float)(atan2f(f.y, f.x) * 180 / 3.14159265358979323846);
+        // ripcurrents_module.cpp:1030 calls libm's float atan2, whose last bit differs from platform to platform (and from
+        // the device's atan2f): the angle is evaluated in double and rounded once -- the correctly rounded float, which is
+        // what the oracle pins too -- so the truncation to the hue byte below cannot flip
+        float theta = (float)((float)atan2((double)f.y, (double)f.x) * 180 / 3.14159265358979323846);
         theta += theta < 0 ? 360 : 0;
         float mag = sqrtf(f.x * f.x + f.y * f.y);
         uint8_t* q = hsv + (size_t)y * hsv_step + 3 * x;
@@ -958,10 +963,12 @@ extern "C" int rcflow_histogram_device_ptr(rc_ctx* ctx, int stream, int32_t** d_
     return RC_OK;
 }
 
-extern "C" int rcflow_classify_accumulate_dev(rc_ctx* ctx, int stream, const float* d_flow, size_t flow_step,
-                                              int w, int h, int framecount, float MID, float LOWER,
-                                              float* d_polar, size_t polar_step, float* d_wclass, size_t wc_step,
-                                              float* d_out, size_t out_step, uint8_t* d_mask, size_t mask_step) {
+int rc_analysis_ensure(rc_ctx* ctx, RcSlot& s, int w, int h) { return analysis_ensure(ctx, s, w, h, false); }
+
+// framecount < 0: the counter is the slot's device word (an.loopc), incremented by k_loop_count in the same stream
+int rc_classify_accumulate(rc_ctx* ctx, int stream, const float* d_flow, size_t flow_step, int w, int h, int framecount,
+                           float MID, float LOWER, float* d_polar, size_t polar_step, float* d_wclass, size_t wc_step,
+                           float* d_out, size_t out_step, uint8_t* d_mask, size_t mask_step) {
     RcSlot* s = rc_slot(ctx, stream);
     if (!s) return RC_EINVAL;
     int rc = check_flow(d_flow, flow_step, w, h);
@@ -973,13 +980,46 @@ extern "C" int rcflow_classify_accumulate_dev(rc_ctx* ctx, int stream, const flo
     }
     RC_HIP(hipSetDevice(ctx->device));
     if ((rc = analysis_ensure(ctx, *s, w, h, false))) return rc;
-    ClassifyArgs a = {d_flow, flow_step, w, h, framecount, MID, LOWER, (const float*)s->an.thr.p,
+    const int* d_fc = framecount < 0 ? (const int*)s->an.loopc.p : nullptr;
+    if (framecount < 0 && !d_fc) { rc_set_error("no device frame counter"); return RC_ESTATE; }
+    ClassifyArgs a = {d_flow, flow_step, w, h, framecount, d_fc, MID, LOWER, (const float*)s->an.thr.p,
                       (float*)s->an.acc.p, d_polar, polar_step, d_wclass, wc_step, d_out, out_step, d_mask, mask_step};
     {
         RcProfScope ps(ctx, s->cur, RC_K_CLASSIFY, 0, 16. * w * h);
         hipLaunchKernelGGL(k_classify_accumulate, dim3(grid_for((long long)w * h)), dim3(RC_BLOCK), 0, s->cur, a);
     }
     RC_HIP(hipGetLastError());
+    return RC_OK;
+}
+
+extern "C" int rcflow_classify_accumulate_dev(rc_ctx* ctx, int stream, const float* d_flow, size_t flow_step,
+                                              int w, int h, int framecount, float MID, float LOWER,
+                                              float* d_polar, size_t polar_step, float* d_wclass, size_t wc_step,
+                                              float* d_out, size_t out_step, uint8_t* d_mask, size_t mask_step) {
+    if (framecount < 0) { rc_set_error("negative framecount"); return RC_EINVAL; }
+    return rc_classify_accumulate(ctx, stream, d_flow, flow_step, w, h, framecount, MID, LOWER, d_polar, polar_step, d_wclass,
+                                  wc_step, d_out, out_step, d_mask, mask_step);
+}
+
+// the frame counter of rcflow_frame_loop_step: set (host value) or advanced by one, in stream order
+__global__ void k_loop_count(int* c, int set, int value) { *c = set ? value : *c + 1; }
+int rc_loop_counter(rc_ctx* ctx, RcSlot& s, bool set, int value) {
+    int rc;
+    if ((rc = rc_buf_ensure(s.an.loopc, 16))) return rc;
+    hipLaunchKernelGGL(k_loop_count, dim3(1), dim3(1), 0, s.cur, (int*)s.an.loopc.p, set ? 1 : 0, value);
+    RC_HIP(hipGetLastError());
+    (void)ctx;
+    return RC_OK;
+}
+// what rcflow_histogram_dev books on the host for one more w x h field (the graph replay of rcflow_frame_loop_step
+// runs the kernels without passing through it)
+int rc_hist_book(RcSlot& s, int w, int h, bool commit) {
+    if (s.an.hist_added + (long long)w * h > 0x7fffffffll) {
+        rc_set_error("the flow histogram's int32 counters would wrap (%lld pixels counted): "
+                     "start a new segment with rcflow_histogram_reset_dev", s.an.hist_added);
+        return RC_ESTATE;
+    }
+    if (commit) s.an.hist_added += (long long)w * h;
     return RC_OK;
 }
 

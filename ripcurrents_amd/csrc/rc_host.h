@@ -37,6 +37,7 @@ struct RcAnalysis {
     RcBuf dist;        // h*w float streamlines_distance
     RcBuf scratch;     // reductions
     RcBuf jet;         // COLORMAP_JET LUT (768 B) + the display maximum key
+    RcBuf loopc;       // one int32: framecount of rcflow_frame_loop_step (incremented on the device)
 };
 
 struct RcBatchKey {
@@ -80,6 +81,12 @@ struct RcSlot {
     void* batch_exec[2] = {nullptr, nullptr};
     int batch_eager[2] = {0, 0};
     RcBatchKey batch_key[2] = {};
+    // rcflow_frame_loop_step: one captured launch sequence per ring parity, the configuration they were captured for,
+    // the stream's flow-field counter (host copy; the kernels read the device word an.loopc)
+    void* loop_exec[2] = {nullptr, nullptr};
+    int loop_eager[2] = {0, 0};
+    unsigned char loop_key[2][160] = {};
+    int loop_fc = 0;
     RcAnalysis an;
 };
 
@@ -126,6 +133,14 @@ int rc_buf_ensure(RcBuf& b, size_t bytes);
 void rc_buf_free(RcBuf& b);
 RcSlot* rc_slot(rc_ctx* ctx, int stream);
 void rc_batch_graph_drop(RcSlot& s);
+void rc_loop_graph_drop(RcSlot& s);
+// analysis_kernels.hip, for rcflow_frame_loop_step
+int rc_classify_accumulate(rc_ctx* ctx, int stream, const float* d_flow, size_t flow_step, int w, int h, int framecount,
+                           float MID, float LOWER, float* d_polar, size_t polar_step, float* d_wclass, size_t wc_step,
+                           float* d_out, size_t out_step, uint8_t* d_mask, size_t mask_step);
+int rc_loop_counter(rc_ctx* ctx, RcSlot& s, bool set, int value);
+int rc_hist_book(RcSlot& s, int w, int h, bool commit);
+int rc_analysis_ensure(rc_ctx* ctx, RcSlot& s, int w, int h);
 
 struct RcProfScope {
     rc_ctx* ctx;

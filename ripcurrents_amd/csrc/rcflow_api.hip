@@ -214,7 +214,8 @@ static void slot_free(RcSlot& s) {
     s.pin_bytes = 0;
     for (auto& b : s.stage_f32) rc_buf_free(b);
     rc_buf_free(s.an.hist); rc_buf_free(s.an.hist_part); rc_buf_free(s.an.thr); rc_buf_free(s.an.acc);
-    rc_buf_free(s.an.pt); rc_buf_free(s.an.dist); rc_buf_free(s.an.scratch); rc_buf_free(s.an.jet);
+    rc_buf_free(s.an.pt); rc_buf_free(s.an.dist); rc_buf_free(s.an.scratch); rc_buf_free(s.an.jet); rc_buf_free(s.an.loopc);
+    rc_loop_graph_drop(s);
     for (auto& e : s.fev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     for (auto& e : s.flow_done) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     if (s.own) (void)hipStreamDestroy(s.own);
@@ -263,6 +264,18 @@ extern "C" int rcflow_debug_read_stamps(rc_ctx* ctx, long long* out, int n) {
     RC_HIP(hipDeviceSynchronize());
     RC_HIP(hipMemcpy(out, ctx->stamps, (size_t)n * 8, hipMemcpyDeviceToHost));
     return RC_OK;
+}
+
+// Diagnostic (not part of include/rcflow.h; scripts/r3/level_errors.py): the flow field a scale's last launch wrote
+// for pair 0 of the slot's last call -- valid for scales >= 1 after a call whose iterations fit one or two launches
+// per scale (buffer A then B alternate); which = 0 / 1 picks the buffer.
+extern "C" int rcflow_debug_level_flow_ptr(rc_ctx* ctx, int stream, int level, int which, float** d_flow, int* w, int* h) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !s->plan.valid || level < 0 || level >= s->plan.nlev || !d_flow) return RC_EINVAL;
+    *d_flow = (float*)(which ? s->FB[level].p : s->FA[level].p);
+    if (w) *w = s->plan.lv[level].w;
+    if (h) *h = s->plan.lv[level].h;
+    return *d_flow ? RC_OK : RC_ESTATE;
 }
 
 extern "C" int rcflow_set_option(rc_ctx* ctx, const char* name, int value) {
@@ -546,6 +559,7 @@ static int ensure_plan(rc_ctx* ctx, RcSlot& s, int w, int h, const rc_farneback_
         pl.nslots == nslots && pl.exact_taps == ctx->exact_taps && pl.exact == exact)
         return RC_OK;
     rc_batch_graph_drop(s);
+    rc_loop_graph_drop(s);
     RC_HIP(hipStreamSynchronize(s.cur));
     if (s.aux) RC_HIP(hipStreamSynchronize(s.aux));
     pl.valid = false;
@@ -1213,6 +1227,146 @@ extern "C" int rcflow_farneback_clip_dev(rc_ctx* ctx, int stream, const uint8_t*
     }
     cleanup();
     return rc;
+}
+
+// ---------------------------------------------------------------------------- the whole frame loop, one launch per frame
+void rc_loop_graph_drop(RcSlot& s) {
+    for (int i = 0; i < 2; i++) {
+        if (s.loop_exec[i]) (void)hipGraphExecDestroy((hipGraphExec_t)s.loop_exec[i]);
+        s.loop_exec[i] = nullptr;
+        s.loop_eager[i] = 0;
+    }
+}
+
+struct RcLoopKey {          // everything a captured launch sequence has baked in
+    rc_frame_loop loop;
+    int w, h, pin, ring, ablate, chain;
+    void* hip_stream;
+    void* d_frame; void* pin_host; void* d_flow;
+};
+static_assert(sizeof(RcLoopKey) <= sizeof(((RcSlot*)nullptr)->loop_key[0]), "RcSlot::loop_key too small");
+
+// the analysis chain of one frame on the resident flow field (ripcurrents.cpp:229-479), on s.cur
+static int loop_analysis(rc_ctx* ctx, RcSlot& s, int stream, const rc_frame_loop& L, int w, int h) {
+    const size_t fs = (size_t)w * 8;
+    float* d_flow = (float*)s.stage_flow.p;
+    int rc;
+    if ((rc = rc_loop_counter(ctx, s, false, 0))) return rc;                                          // framecount++ (ripcurrents.cpp:194)
+    if ((rc = rcflow_advect_field_dev(ctx, stream, d_flow, fs, w, h, L.dt, L.iterations, -1.f))) return rc;     // :229-231, last frame's UPPER
+    if (L.nseeds > 0 && (rc = rcflow_advect_points_dev(ctx, stream, L.d_seeds, L.nseeds, d_flow, fs, w, h, L.seed_dt, L.seed_iterations,
+                                                       L.seed_upper, L.seed_variant, nullptr))) return rc;      // :283-285
+    if ((rc = rcflow_histogram_dev(ctx, stream, d_flow, fs, w, h))) return rc;                          // :319-330
+    if ((rc = rcflow_thresholds_dev(ctx, stream))) return rc;                                           // :333-366
+    if ((rc = rc_classify_accumulate(ctx, stream, d_flow, fs, w, h, -1, L.MID, L.LOWER, nullptr, 0, nullptr, 0, nullptr, 0,
+                                     L.d_outmask, L.mask_step))) return rc;                               // :376-439
+    if (L.d_edges && (rc = rcflow_create_edges_dev(ctx, stream, L.d_outmask, L.mask_step, w, h, L.d_edges, L.edges_step))) return rc;   // :477-479
+    return RC_OK;
+}
+
+// upload + expansion + flow + the analysis chain of one frame on s.cur (eager or under stream capture)
+static int loop_launches(rc_ctx* ctx, RcSlot& s, int stream, const rc_frame_loop& L, int pin, int w, int h) {
+    const size_t fb = (size_t)w * h, fs = (size_t)w * 8;
+    uint8_t* d_frame = (uint8_t*)s.stage_u8.p + (size_t)pin * fb;
+    float* d_flow = (float*)s.stage_flow.p;
+    const int cur = s.cur_slot, nxt = cur ^ 1;
+    RC_HIP(hipMemcpyAsync(d_frame, s.pin[pin], fb, hipMemcpyHostToDevice, s.cur));
+    int rc;
+    if ((rc = expand_frames(ctx, s, d_frame, 0, w, 1, nxt))) return rc;
+    if ((rc = compute_flows(ctx, s, 1, cur, d_flow, 0, fs, nxt))) return rc;
+    return loop_analysis(ctx, s, stream, L, w, h);
+}
+
+static int push_staged_frame(rc_ctx* ctx, RcSlot* s, int stream, int i, int w, int h, const rc_farneback_params* p);
+
+extern "C" int rcflow_frame_loop_step(rc_ctx* ctx, int stream, const rc_farneback_params* p, const rc_frame_loop* loop) {
+    RcSlot* s = rc_slot(ctx, stream);
+    if (!s || !p || !loop) { if (s) rc_set_error("null argument"); return RC_EINVAL; }
+    if (s->pin_acq < 0 || s->pin_acq != s->pin_i) { rc_set_error("no frame buffer acquired (rcflow_frame_buffer_acquire) since the last push"); return RC_ESTATE; }
+    if (loop->nseeds < 0 || (loop->nseeds && !loop->d_seeds) || (loop->d_edges && !loop->d_outmask) || loop->iterations < 0) {
+        rc_set_error("bad frame-loop configuration");
+        return RC_EINVAL;
+    }
+    RC_HIP(hipSetDevice(ctx->device));
+    const int w = s->pin_w, h = s->pin_h, pin = s->pin_acq;
+    int rc;
+    if (!loop->use_graph) {
+        // The default: the two-stream frame push (upload and expansion of this frame beside the previous frame's flow
+        // and analysis kernels, which the slot's stream may still be executing) followed by the analysis launches --
+        // measured faster than one linear captured sequence per frame, which cannot overlap across frames
+        if ((rc = rc_analysis_ensure(ctx, *s, w, h))) return rc;
+        rc = push_staged_frame(ctx, s, stream, pin, w, h, p);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            s->loop_fc = 0;
+            if ((rc = rc_loop_counter(ctx, *s, true, 0))) return rc;
+            return 1;
+        }
+        if ((rc = loop_analysis(ctx, *s, stream, *loop, w, h))) return rc;
+        s->loop_fc++;
+        return RC_OK;
+    }
+    const bool was_valid = s->plan.valid;
+    rc = ensure_plan(ctx, *s, w, h, p, 1, 2);                // a ring of two expansions: the captured sequences alternate
+    if (rc) return rc;
+    if (!was_valid) s->primed = 0;
+    s->batch_primed = 0;
+    if ((rc = rc_analysis_ensure(ctx, *s, w, h))) return rc;
+    const size_t fb = (size_t)w * h;
+    if (!s->primed) {
+        rc_loop_graph_drop(*s);
+        uint8_t* d_frame = (uint8_t*)s->stage_u8.p + (size_t)pin * fb;
+        RC_HIP(hipMemcpyAsync(d_frame, s->pin[pin], fb, hipMemcpyHostToDevice, s->cur));
+        RC_HIP(hipEventRecord(s->pin_free[pin], s->cur));
+        if ((rc = expand_frames(ctx, *s, d_frame, 0, w, 1, 0))) return rc;
+        s->loop_fc = 0;
+        if ((rc = rc_loop_counter(ctx, *s, true, 0))) return rc;
+        s->primed = 1; s->cur_slot = 0;
+        s->pin_i = pin ^ 1; s->pin_acq = -1;
+        s->flow_w = s->flow_h = 0;
+        return 1;
+    }
+    const int cur = s->cur_slot;
+    if (cur > 1) { rc_set_error("the slot's ring is not the frame loop's: call rcflow_stream_reset first"); return RC_ESTATE; }
+    RcLoopKey key;
+    memset(&key, 0, sizeof(key));
+    key.loop = *loop;
+    key.w = w; key.h = h; key.pin = pin; key.ring = cur; key.ablate = ctx->ablate; key.chain = ctx->chain;
+    key.hip_stream = (void*)s->cur;
+    key.d_frame = (uint8_t*)s->stage_u8.p + (size_t)pin * fb; key.pin_host = s->pin[pin]; key.d_flow = s->stage_flow.p;
+    const bool graph_ok = !ctx->prof_on && s->cur != nullptr;
+    const bool same = !memcmp(&key, s->loop_key[cur], sizeof(key));
+    if (graph_ok && s->loop_exec[cur] && same) {
+        // steady state: one launch replays the frame's whole sequence; what the eager calls book on the host is booked here
+        if ((rc = rc_hist_book(*s, w, h, true))) return rc;
+        RC_HIP(hipGraphLaunch((hipGraphExec_t)s->loop_exec[cur], s->cur));
+        s->ts_streak = 0;
+    } else if (graph_ok && s->loop_eager[cur] && same) {
+        // second frame of this parity with the same configuration: capture the sequence while issuing it, then launch it
+        if ((rc = rc_hist_book(*s, w, h, false))) return rc;
+        hipGraph_t graph = nullptr;
+        RC_HIP(hipStreamBeginCapture(s->cur, hipStreamCaptureModeRelaxed));
+        rc = loop_launches(ctx, *s, stream, *loop, pin, w, h);
+        hipError_t e = hipStreamEndCapture(s->cur, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess || !graph) { rc_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return RC_EHIP; }
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { rc_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e)); return RC_EHIP; }
+        s->loop_exec[cur] = exec;
+        RC_HIP(hipGraphLaunch(exec, s->cur));
+    } else {
+        if (s->loop_exec[cur]) { (void)hipGraphExecDestroy((hipGraphExec_t)s->loop_exec[cur]); s->loop_exec[cur] = nullptr; }
+        if ((rc = loop_launches(ctx, *s, stream, *loop, pin, w, h))) return rc;
+        memcpy(s->loop_key[cur], &key, sizeof(key));
+        s->loop_eager[cur] = 1;
+    }
+    RC_HIP(hipEventRecord(s->pin_free[pin], s->cur));        // (behind the whole frame: the staging buffer comes round two frames later)
+    s->cur_slot = cur ^ 1;
+    s->pin_i = pin ^ 1; s->pin_acq = -1;
+    s->flow_w = w; s->flow_h = h;
+    s->loop_fc++;
+    return RC_OK;
 }
 
 // ---------------------------------------------------------------------------- lockstep batch of streams

@@ -27,8 +27,11 @@ import os
 import numpy as np
 
 WELL = 1e-2          # determinant threshold of SURVEY.md 8(d)
-BARS = {"config": dict(p999_well=1e-3, max_well=5e-3, max_rest=5e-2),
-        "stress": dict(p999_well=1e-2, max_well=5e-2, max_rest=5e-2)}
+# max_path: the maximum over pixels whose WHOLE coarse-to-fine path is well conditioned (det_min > 1e-2) -- where 8(d)'s
+# premise holds at every solve that fed the pixel, its figure (1e-3 px) is asserted literally.  Deep pyramids (five scales
+# at 4K) pass `max_path=...` with the measured reason: see assert_conditioned.
+BARS = {"config": dict(p999_well=1e-3, max_well=5e-3, max_rest=5e-2, max_path=1e-3),
+        "stress": dict(p999_well=1e-2, max_well=5e-2, max_rest=5e-2, max_path=5e-2)}
 
 
 def conditioned_stats(got, ref, det_last, det_min):
@@ -45,13 +48,18 @@ def conditioned_stats(got, ref, det_last, det_min):
     return s
 
 
-def assert_conditioned(name, got, ref, det_last, det_min, tier="config"):
+def assert_conditioned(name, got, ref, det_last, det_min, tier="config", max_path=None):
+    """max_path overrides the tier's bar on path-conditioned pixels for a named configuration (BASELINE.md states the
+    measured figure beside it)."""
     s = conditioned_stats(got, ref, det_last, det_min)
     print("\n[parity 8(d) %s] %s: %s" % (tier, name, s))
     if os.environ.get("RC_PARITY_REPORT_ONLY"):
         return s
-    b = BARS[tier]
+    b = dict(BARS[tier])
+    if max_path is not None:
+        b["max_path"] = max_path
     assert np.isfinite(np.asarray(got)).all(), name
     assert s["p999_well"] <= b["p999_well"] and s["max_well"] <= b["max_well"], (name, s)
     assert s["max_rest"] <= b["max_rest"], (name, s)
+    assert s["max_path"] <= b["max_path"], (name, s)
     return s

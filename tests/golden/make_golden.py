@@ -24,11 +24,21 @@ from ripcurrents_amd import synth  # noqa: E402
 def main():
     clip = synth.surf_clip(96, 80, 2, seed=1234)
     p = dict(pyr_scale=0.5, levels=2, winsize=3, iters=2, poly_n=15, poly_sigma=1.2, flags=0)
-    flow = oracle.farneback(clip[0], clip[1], **p)
-    np.savez_compressed(os.path.join(HERE, "farneback_rc215_96x80.npz"), prev=clip[0], next=clip[1], flow=flow, **p)
+    # every Farneback fixture carries the conditioning of its pixels (determinant of the final solve, minimum along the
+    # coarse-to-fine path), so that the GPU test applies SURVEY 8(d)'s conditioned metric to it
+    flow, dl, dm = oracle.farneback_diag(clip[0], clip[1], **p)
+    np.savez_compressed(os.path.join(HERE, "farneback_rc215_96x80.npz"), prev=clip[0], next=clip[1], flow=flow,
+                        det_last=dl.astype(np.float32), det_min=dm, **p)
     p2 = dict(p, flags=256, winsize=10, iters=3)
-    flow2 = oracle.farneback(clip[0], clip[1], **p2)
-    np.savez_compressed(os.path.join(HERE, "farneback_main1119_96x80.npz"), prev=clip[0], next=clip[1], flow=flow2, **p2)
+    flow2, dl2, dm2 = oracle.farneback_diag(clip[0], clip[1], **p2)
+    np.savez_compressed(os.path.join(HERE, "farneback_main1119_96x80.npz"), prev=clip[0], next=clip[1], flow=flow2,
+                        det_last=dl2.astype(np.float32), det_min=dm2, **p2)
+    # half the reference's working size (ripcurrents.hpp:4-5) with the parameters of ripcurrents.cpp:215: three full scales
+    # (no level cropped), enough interior for the conditioned metric to bite, ~1 MB
+    clip320 = synth.surf_clip(320, 240, 2, seed=4321)
+    flow4, dl4, dm4 = oracle.farneback_diag(clip320[0], clip320[1], **p)
+    np.savez_compressed(os.path.join(HERE, "farneback_rc215_320x240.npz"), prev=clip320[0], next=clip320[1], flow=flow4,
+                        det_last=dl4.astype(np.float32), det_min=dm4, **p)
     # main.cpp:264 (Gaussian winsize 3): the library's default path for it is upstream's operation order, so this one
     # must be reproduced bit for bit by the HIP path; the determinants of the final solves travel with it
     p3 = dict(p, flags=256)
