@@ -103,10 +103,10 @@ int rcflow_use_own_stream(rc_ctx* ctx, int stream);
  * frame t+1 beside the flow kernels of frame t; 1 = rcflow_push_frame_u8 only (the library owns the upload), 2 = also
  * rcflow_push_frame_dev, the caller then guaranteeing that d_frame is complete when the call is made; "merge_small" (1) merged launches for calls of one or two frames; "fuse_pyr" (1)
  * pyramid scales 1 and 2 written by the scale-0 expansion launch (pyr_scale 0.5, exact half / quarter sizes);
- * "ablate" bit field selecting earlier kernel forms for A/B runs
- * (64 LDS-resident flow kernel, 128 / 256 / 512 other flow tiles, 2048 byte-wise u8 staging, 4096 earlier
- * pyramid kernels, 8192 earlier large-window kernel, 65536 tile kernel for Gaussian winsize 10 / 20; the full list is
- * enum RcAblate in csrc/rc_common.h); "stamps" diagnostic builds only. */
+ * "ablate" bit field selecting alternative kernel forms for A/B runs and the bit-identity tests (2048 byte-wise u8
+ * staging, 4096 earlier pyramid kernels, 8192 generic large-window kernel, 65536 tile kernel for Gaussian winsize
+ * 10 / 20, 33554432 tile chains whatever the launch size; the full list is enum RcAblate in csrc/rc_common.h);
+ * "stamps" diagnostic builds only. */
 int rcflow_set_option(rc_ctx* ctx, const char* name, int value);
 
 /* ------------------------------------------------------------------ A: Farneback

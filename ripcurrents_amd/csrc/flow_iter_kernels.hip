@@ -23,23 +23,8 @@
 #include "rc_device.h"
 
 #define RC_ITER_BATCH 3
-#ifndef RC_RR_ABL
-#define RC_RR_ABL 0       // timing-only ablations of k_flow_iter2_rr (never in the product): 1 = the loads alone, 2 = no global loads
-#endif
 #ifndef RC_RR_D
 #define RC_RR_D 3         // displacements below this many pixels are served from the LDS window (28 x 28 tile)
-#endif
-#ifndef RC_DB_SPREAD
-#define RC_DB_SPREAD 1    // k_flow_iter2_db: the next tile's loads issued piecewise across the compute phase (0: in one burst)
-#endif
-#ifndef RC_DB_ABL
-#define RC_DB_ABL 0       // timing-only cuts of k_flow_iter2_db: 1 = no global loads, 2 = the loads alone, 3 = no wait for the prefetch
-#endif
-#ifndef RC_RR_PRIO
-#define RC_RR_PRIO 0      // k_flow_iter2_rr experiment: wave priority per block (1: blockIdx & 3, 2: (blockIdx >> 3) & 3, 3: HW thread-group slot & 3), per phase (4: loads high, 5: compute high)
-#endif
-#ifndef RC_RR_WPAD
-#define RC_RR_WPAD 0      // extra texels per LDS row of the register-row kernel's R1 window (see k_flow_iter2_rr)
 #endif
 
 // This file is compiled twice.  The default build (namespace rc_flow_fast) is the fast arithmetic:
@@ -807,47 +792,6 @@ static void launch_w3(RcIterArgs a, int pairs, hipStream_t s) {
     hipLaunchKernelGGL((k_flow_iter_w3<IN_MODE, G>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(RC_W3_THREADS), lds, s, a);
 }
 
-// ------------------------------------------------------------------------------------
-// TWO iterations in one launch (3x3 window).  Both iterations of a scale read the same R0
-// and R1, and iteration 2 needs iteration 1's flow only at the pixel itself, so a block
-// can run   M0 (tile + 2 halo) -> flow1 (tile + 1 halo) -> M1 -> flow2 (tile)   entirely
-// on chip: R0 stays in registers, flow1 never exists in memory, and R1's second gather
-// (at p + flow1) hits the lines the first one just brought in.  HBM bytes per pixel drop
-// from 2 x 56 to about 56.  Arithmetic is operation-for-operation that of two launches of
-// k_flow_iter_w3 (bit-identical results).
-// 3x3 window of the five LDS planes around (ly, lx) + solve.
-template <int GAUSS_>
-__device__ __forceinline__ float2 rc_window3_solve(const float* Ms, int plane, int pitch, int ly, int lx,
-                                                   const RcWindow& win) {
-    float g[5];
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        const float* mc = Ms + c * plane + (ly - 1) * pitch + (lx - 1);
-        float v[3];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            float up = mc[j], mid = mc[pitch + j], dn = mc[2 * pitch + j];
-            if (GAUSS_) v[j] = mid * win.k[0] + (dn + up) * win.k[1];
-            else v[j] = mid + (dn + up);
-        }
-        if (GAUSS_) g[c] = v[1] * win.k[0] + win.k[1] * (v[0] + v[2]);
-        else g[c] = (v[1] + v[0]) + v[2];
-    }
-    return rc_solve3(g, GAUSS_ ? 1e-3f : (float)win.box_eps);
-}
-
-// Direct global -> LDS load (no VGPR destination).  `lds_wave_base` is the LDS address for lane 0
-// of the wave; lane l lands at lds_wave_base + l * BYTES.
-// (the size argument of the builtin must be a literal)
-__device__ __forceinline__ void rc_glds16(const void* g, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-__device__ __forceinline__ void rc_glds4(const void* g, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
-}
-
 // Bilinear gather of the 5 coefficients of R1 at p + flow: from the block's LDS window when
 // the 2x2 footprint lies inside it (|flow| < D), else from global memory.
 template <int WW, int WH, int WP = WW>
@@ -872,245 +816,16 @@ __device__ __forceinline__ void rc_gather_window(RcGather& g, const float4* LA, 
     }
 }
 
-// D = half-width of the R1 window beyond the tile+halo region: displacements |flow| < D are
-// served from LDS.  One block = ONE memory round trip: flow_in, R0 and the R1 window do not
-// depend on each other, so all of a thread's global loads are issued before the first use.
-template <int IN_MODE, int GAUSS_, int TW, int TH, int NT, int D>
-__global__ __launch_bounds__(NT, 4) void k_flow_iter2_w3(RcIterArgs a) {
-    constexpr int MW = TW + 4, MH = TH + 4, MP = MW | 1, PLANE = MH * MP;
-    constexpr int NIT = 3, NGRP = (MH + NIT - 1) / NIT;       // a thread owns NIT vertically adjacent pixels
-    constexpr int WW = MW + 2 * D, WH = MH + 2 * D, WN = WW * WH, NWL = (WN + NT - 1) / NT;
-    static_assert(MW * NGRP <= NT, "tile does not fit the block");
-    extern __shared__ __align__(16) float smf[];
-    constexpr int WNP = (WN + 63) & ~63;    // whole waves of LDS-DMA
-    float4* LA = (float4*)smf;              // [WH][WW]  R1 (y, x, yy, xx)
-    float* LB = smf + 4 * WNP;              // [WH][WW]  R1 xy
-    float* Ms = LB + WNP;                   // [5][MH][MP]: M0 (halo 2), later M1 (halo 1) in place
-    const int tid = threadIdx.x;
-    const int z = blockIdx.y;
-    const int t = a.xcd_remap ? rc_xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y) : (int)blockIdx.x;
-    const int tx0 = (t % a.tiles_x) * TW, ty0 = (t / a.tiles_x) * TH;
-    const int w = a.w, h = a.h;
-    const size_t s0 = (size_t)((a.slot0 + z * a.zstep) % a.nslots) * a.R_slot_stride;
-    const size_t s1 = (size_t)((a.slot1 + z * a.zstep) % a.nslots) * a.R_slot_stride;
-    const float4* __restrict__ RA0 = a.RA + s0;  const float* __restrict__ RB0 = a.RB + s0;
-    const float4* __restrict__ RA1 = a.RA + s1;  const float* __restrict__ RB1 = a.RB + s1;
-    const float2* __restrict__ fin = a.fin + (size_t)z * a.fin_pair_stride;
-    char* fout = a.fout + (size_t)z * a.fout_pair_stride;
-    const int ox = tx0 - 2 - D, oy = ty0 - 2 - D;             // window origin (image coordinates)
-#ifdef RC_STAMPS   // diagnostic build only (make STAMPS=1; scripts/exp_stamps.py)
-    const bool stamp = a.stamps && tid == 0 && (blockIdx.x % 61) == 0 && z == 0;
-    long long* st = a.stamps ? a.stamps + (size_t)(blockIdx.x / 61) * 8 : nullptr;
-#define RC_STAMP(i) if (stamp) st[i] = __builtin_amdgcn_s_memtime()
-#else
-#define RC_STAMP(i)
-#endif
-    RC_STAMP(0);
-
-    const bool owner = tid < MW * NGRP;
-    const int lxo = owner ? tid % MW : 0, ly0 = owner ? (tid / MW) * NIT : 0;
-    const int gxo = rc_clampi(tx0 - 2 + lxo, 0, w - 1);
-    int gys[NIT];
-#pragma unroll
-    for (int q = 0; q < NIT; q++) gys[q] = rc_clampi(ty0 - 2 + min(ly0 + q, MH - 1), 0, h - 1);
-#define RC_GY(q) gys[q]
-    // blocks whose tile + halo stays 5 px away from every image border skip the border-scale
-    // table and the replicate-padding special cases (block-uniform branch)
-    const bool interior = tx0 - 2 >= 5 && tx0 + TW + 2 <= w - 5 && ty0 - 2 >= 5 && ty0 + TH + 2 <= h - 5;
-
-    // ---- every global load of the block, issued together -------------------------------
-    // The R1 window goes straight to LDS (global_load_lds: per-lane source address, LDS
-    // destination = wave-uniform base + lane * size), so it costs no VGPRs and no ds_write.
-    {
-        const int wave_base = tid & ~63;
-#pragma unroll
-        for (int q = 0; q < NWL; q++) {
-            int idx = tid + q * NT;
-            int wy = idx / WW, wx = idx - wy * WW;
-            int gx = ox + wx, gy = oy + wy;
-            bool ok = idx < WN && (unsigned)gx < (unsigned)w && (unsigned)gy < (unsigned)h;
-            size_t p = ok ? (size_t)gy * w + gx : 0;      // out-of-image texels are never read
-            if (q * NT + wave_base < WN) {                // wave-uniform: whole waves past the window skip
-                rc_glds16(RA1 + p, LA + (q * NT + wave_base));
-                rc_glds4(RB1 + p, LB + (q * NT + wave_base));
-            }
-        }
-    }
-    float4 A0[NIT];
-    float B0[NIT];
-#pragma unroll
-    for (int q = 0; q < NIT; q++) {
-        size_t p0 = (size_t)RC_GY(q) * w + gxo;
-        A0[q] = RA0[p0];
-        B0[q] = RB0[p0];
-    }
-    float dx[NIT], dy[NIT];
-    if constexpr (IN_MODE == 0) {
-#pragma unroll
-        for (int q = 0; q < NIT; q++) dx[q] = dy[q] = 0.f;
-    } else if constexpr (IN_MODE == 1) {
-        float2 d[NIT];
-#pragma unroll
-        for (int q = 0; q < NIT; q++) d[q] = fin[(size_t)RC_GY(q) * w + gxo];
-#pragma unroll
-        for (int q = 0; q < NIT; q++) { dx[q] = d[q].x; dy[q] = d[q].y; }
-    } else {
-        float2 p00[NIT], p01[NIT], p10[NIT], p11[NIT];
-        float ax, ay[NIT];
-        const int sx = rc_src_x(gxo, a.up_scale_x, a.fin_w, ax);
-        const int sx1 = min(sx + 1, a.fin_w - 1);
-#pragma unroll
-        for (int q = 0; q < NIT; q++) {
-            int sy = rc_src_y(RC_GY(q), a.up_scale_y, ay[q]);
-            int sy0 = rc_clampi(sy, 0, a.fin_h - 1), sy1 = rc_clampi(sy + 1, 0, a.fin_h - 1);
-            const float2* S0 = fin + (size_t)sy0 * a.fin_w;
-            const float2* S1 = fin + (size_t)sy1 * a.fin_w;
-            p00[q] = S0[sx]; p01[q] = S0[sx1]; p10[q] = S1[sx]; p11[q] = S1[sx1];
-        }
-#pragma unroll
-        for (int q = 0; q < NIT; q++) {
-            float a0 = 1.f - ax, a1 = ax, b0 = 1.f - ay[q], b1 = ay[q];
-            float r0x = p00[q].x * a0 + p01[q].x * a1, r1x = p10[q].x * a0 + p11[q].x * a1;
-            float r0y = p00[q].y * a0 + p01[q].y * a1, r1y = p10[q].y * a0 + p11[q].y * a1;
-            dx[q] = (r0x * b0 + r1x * b1) * a.up_mul;
-            dy[q] = (r0y * b0 + r1y * b1) * a.up_mul;
-        }
-    }
-    RC_STAMP(1);
-    __syncthreads();      // (the compiler drains the pending LDS-DMA with vmcnt(0) here)
-    RC_STAMP(2);
-
-    // ---- iteration 1 matrices (R0 stays in registers for iteration 2).  The R1 samples come
-    // from LDS, so one pixel at a time is enough and keeps the register count down.
-#pragma unroll
-    for (int q = 0; q < NIT; q++) {
-        RcGather g;
-        rc_gather_window<WW, WH>(g, LA, LB, ox, oy, RA1, RB1, gxo, RC_GY(q), dx[q], dy[q], w, h);
-        RcM5 v = rc_matrices_reg(A0[q], B0[q], g, dx[q], dy[q], gxo, RC_GY(q), w, h, !interior);
-        if (owner && ly0 + q < MH) {
-            float* mp = Ms + (ly0 + q) * MP + lxo;
-            mp[0] = v.m0; mp[PLANE] = v.m1; mp[2 * PLANE] = v.m2; mp[3 * PLANE] = v.m3; mp[4 * PLANE] = v.m4;
-        }
-    }
-    __syncthreads();
-    RC_STAMP(3);
-    if (a.ablate & RC_ABL_STAGE_A_ONLY) {              // ablation: stage A only
-        if (Ms[tid] == 12345.678f) *(float*)fout = 1.f;
-        return;
-    }
-    // ---- flow1 at tile + 1 halo (the pixels this thread already owns), then its gathers.
-    // The flow of a halo position outside the image is the flow of the pixel it replicates,
-    // so the window is centred on that pixel's own LDS position.
-    // Each thread's three pixels are vertically adjacent LDS rows: one 5x3 read per plane.  Rows
-    // and columns of the read block are clamped into the planes; what that distorts are only
-    // positions that are not iteration-2 pixels (outer ring) -- their results are never stored.
-    RcM5 m1[NIT];
-    {
-        float gs[NIT][5];
-        int rr[NIT + 2];
-#pragma unroll
-        for (int r = 0; r < NIT + 2; r++) rr[r] = rc_clampi(ly0 - 1 + r, 0, MH - 1) * MP;
-        const int c0 = max(lxo - 1, 0), c1 = lxo, c2 = min(lxo + 1, MW - 1);
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-            const float* mc = Ms + c * PLANE;
-            float col[3][NIT + 2];
-#pragma unroll
-            for (int r = 0; r < NIT + 2; r++) {
-                col[0][r] = mc[rr[r] + c0];
-                col[1][r] = mc[rr[r] + c1];
-                col[2][r] = mc[rr[r] + c2];
-            }
-#pragma unroll
-            for (int q = 0; q < NIT; q++) {
-                float v[3];
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    if (GAUSS_) v[j] = col[j][q + 1] * a.win.k[0] + (col[j][q + 2] + col[j][q]) * a.win.k[1];
-                    else v[j] = col[j][q + 1] + (col[j][q + 2] + col[j][q]);
-                }
-                if (GAUSS_) gs[q][c] = v[1] * a.win.k[0] + a.win.k[1] * (v[0] + v[2]);
-                else gs[q][c] = (v[1] + v[0]) + v[2];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NIT; q++) {
-            float2 f1 = rc_solve3(gs[q], GAUSS_ ? 1e-3f : (float)a.win.box_eps);
-            RcGather g;
-            rc_gather_window<WW, WH>(g, LA, LB, ox, oy, RA1, RB1, gxo, RC_GY(q), f1.x, f1.y, w, h);
-            m1[q] = rc_matrices_reg(A0[q], B0[q], g, f1.x, f1.y, gxo, RC_GY(q), w, h, !interior);
-        }
-    }
-    RC_STAMP(4);
-    __syncthreads();      // every thread is done reading M0
-    // M1 is stored for iteration-2 pixels that lie inside the image ...
-    const int px = tx0 - 2 + lxo;
-#pragma unroll
-    for (int q = 0; q < NIT; q++) {
-        const int ly = ly0 + q, py = ty0 - 2 + ly;
-        if (owner && lxo >= 1 && lxo <= MW - 2 && ly >= 1 && ly <= MH - 2 && (unsigned)px < (unsigned)w &&
-            (unsigned)py < (unsigned)h) {
-            float* mp = Ms + ly * MP + lxo;
-            mp[0] = m1[q].m0; mp[PLANE] = m1[q].m1; mp[2 * PLANE] = m1[q].m2; mp[3 * PLANE] = m1[q].m3;
-            mp[4 * PLANE] = m1[q].m4;
-        }
-    }
-    if (!interior) {
-        // ... and positions outside the image replicate the border pixel (the window's
-        // replicate border), copied inside LDS.  Block-uniform branch.
-        __syncthreads();
-        for (int idx = tid; idx < (MW - 2) * (MH - 2); idx += NT) {
-            int ly = 1 + idx / (MW - 2), lx = 1 + idx % (MW - 2);
-            int cx = rc_clampi(tx0 - 2 + lx, 0, w - 1) - (tx0 - 2), cy = rc_clampi(ty0 - 2 + ly, 0, h - 1) - (ty0 - 2);
-            if (cx != lx || cy != ly) {
-#pragma unroll
-                for (int c = 0; c < 5; c++) Ms[c * PLANE + ly * MP + lx] = Ms[c * PLANE + cy * MP + cx];
-            }
-        }
-    }
-#undef RC_GY
-    __syncthreads();
-    RC_STAMP(5);
-    if (a.ablate & RC_ABL_NO_WINDOW) {              // ablation: no final window/solve/store
-        if (Ms[tid] == 12345.678f) *(float*)fout = 1.f;
-        return;
-    }
-    // ---- flow2 on the tile
-    constexpr int RPT = TH / (NT / TW);
-    const int lx = tid % TW, r0 = (tid / TW) * RPT;
-    const int oxp = tx0 + lx;
-    if (oxp < w) {
-#pragma unroll
-        for (int r = 0; r < RPT; r++) {
-            int oyp = ty0 + r0 + r;
-            if (oyp < h)
-                *(float2*)(fout + (size_t)oyp * a.fout_step + (size_t)oxp * 8) =
-                    rc_window3_solve<GAUSS_>(Ms, PLANE, MP, r0 + r + 2, lx + 2, a.win);
-        }
-    }
-    RC_STAMP(6);
-#undef RC_STAMP
-}
-
-template <int IN_MODE, int G, int TW, int TH, int NT, int D>
-static void launch_w3x2_t(RcIterArgs a, int pairs, hipStream_t s) {
-    a.tw = TW; a.th = TH;
-    a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
-    constexpr int WN = (TW + 4 + 2 * D) * (TH + 4 + 2 * D), WNP = (WN + 63) & ~63;
-    size_t lds = sizeof(float) * (5 * WNP + 5 * (TH + 4) * ((TW + 4) | 1));
-    hipLaunchKernelGGL((k_flow_iter2_w3<IN_MODE, G, TW, TH, NT, D>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(NT), lds, s, a);
-}
-
-
-// ===================================================================== two iterations, register-resident M
-// Second form of the fused pair of iterations (the one that runs): the M grid of a block is
-// 32 columns wide = half a wave, a thread owns NIT vertically adjacent positions of one column
-// for ALL stages, and M0 / M1 stay in registers.  The 3x3 window is separable in exactly the
-// order of rc_window3_solve: the vertical 3-sum needs only the rows just above and below the
-// thread's own run (exchanged through a small LDS buffer, two rows per group), the horizontal
-// 3-sum takes its neighbours from the adjacent lanes with DPP wave shifts (v_add_f32_dpp), so
-// the five M planes never go through LDS.  Per tile pixel this is ~1.6x fewer VALU and ~3x
-// fewer LDS instructions than k_flow_iter2_w3 and the same bits.
+// ===================================================================== two iterations in one launch (3x3 window)
+// Both iterations of a scale read the same R0 and R1, and iteration 2 needs iteration 1's flow only at the pixel
+// itself, so a block runs   M0 (tile + 2 halo) -> flow1 (tile + 1 halo) -> M1 -> flow2 (tile)   entirely on chip:
+// flow1 never exists in memory and R1's second gather (at p + flow1) reads the LDS window the first one used.
+// The M grid of a block is 32 columns wide = half a wave, a thread owns NIT vertically adjacent positions of one
+// column for ALL stages, and M0 / M1 stay in registers.  The 3x3 window is separable: the vertical 3-sum needs only
+// the rows just above and below the thread's own run (exchanged through a small LDS buffer, two rows per group), the
+// horizontal 3-sum takes its neighbours from the adjacent lanes with DPP wave shifts (v_add_f32_dpp), so the five M
+// planes never go through LDS or HBM.  Arithmetic is operation for operation that of two launches of k_flow_iter_w3
+// (bit-identical results).
 //   tile = 28 x (8 NIT - 4) outputs, M grid 32 x 8 NIT (halo 2), R1 window = grid +- D in LDS.
 // g[c] = (V[c] + V[c] of lane - 1) + V[c] of lane + 1 for the five planes, as ten v_add_f32_dpp
 // (the compiler's DPP combiner folds only some of the equivalent builtin calls).  s_nop 1 covers
@@ -1309,180 +1024,6 @@ __device__ __forceinline__ void rc_rr_flow_in(const RcIterArgs& a, const float2*
     }
 }
 
-template <int IN_MODE, int GAUSS_, int NIT, int D, int MINB, int MW, int NG>
-__global__ __launch_bounds__(NG * MW, MINB) void k_flow_iter2_rr(RcIterArgs a) {
-    constexpr int NT = NG * MW, MH = NG * NIT, TW = MW - 4, TH = MH - 4;    // NG groups of NIT rows, MW columns
-    // The window's LDS row pitch WP: a wave's two half-waves sample rows NIT apart, so NIT * WP texels must be a
-    // multiple of 32 (512 B of float4s, 128 B of floats) for their 16-byte gathers to run at full rate; the
-    // WP - WW extra texels per row are loaded (they are real neighbours) but never sampled.
-    constexpr int WW = MW + 2 * D, WH = MH + 2 * D, WP = WW + RC_RR_WPAD, WN = WP * WH, NWL = (WN + NT - 1) / NT;
-    constexpr int WNP = (WN + 63) & ~63;    // whole waves of LDS-DMA
-    constexpr int MP = MW + 1, PLANE = MH * MP;
-    static_assert(5 * PLANE <= 5 * WNP, "border-block M1 planes alias the R1 window");
-    extern __shared__ __align__(16) float smf[];
-    float4* LA = (float4*)smf;              // [WH][WW]  R1 (y, x, yy, xx)
-    float* LB = smf + 4 * WNP;              // [WH][WW]  R1 xy
-    float* XR = LB + WNP;                   // [NG][2][5][MW] first / last row of every group
-    float* Ms = smf;                        // border blocks only: [5][MH][MP], after the window is dead
-    const int tid = threadIdx.x;
-    const int z = blockIdx.y;
-    const int t = a.xcd_remap ? rc_xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y) : (int)blockIdx.x;
-    const int tx0 = (t % a.tiles_x) * TW, ty0 = (t / a.tiles_x) * TH;
-    const int w = a.w, h = a.h;
-    const size_t s0 = (size_t)((a.slot0 + z * a.zstep) % a.nslots) * a.R_slot_stride;
-    const size_t s1 = (size_t)((a.slot1 + z * a.zstep) % a.nslots) * a.R_slot_stride;
-    const float4* __restrict__ RA0 = a.RA + s0;  const float* __restrict__ RB0 = a.RB + s0;
-    const float4* __restrict__ RA1 = a.RA + s1;  const float* __restrict__ RB1 = a.RB + s1;
-    const float2* __restrict__ fin = a.fin + (size_t)z * a.fin_pair_stride;
-    char* fout = a.fout + (size_t)z * a.fout_pair_stride;
-    const int ox = tx0 - 2 - D, oy = ty0 - 2 - D;             // window origin (image coordinates)
-
-    const int x = tid & (MW - 1), grp = tid / MW, ly0 = grp * NIT;
-    const int px = tx0 - 2 + x;
-    const int gxo = rc_clampi(px, 0, w - 1);
-    int gys[NIT];
-#pragma unroll
-    for (int q = 0; q < NIT; q++) gys[q] = rc_clampi(ty0 - 2 + ly0 + q, 0, h - 1);
-    const bool interior = tx0 - 2 >= 5 && tx0 - 2 + MW <= w - 5 && ty0 - 2 >= 5 && ty0 - 2 + MH <= h - 5;
-#if RC_RR_PRIO == 4 || RC_RR_PRIO == 5
-    __builtin_amdgcn_s_setprio(RC_RR_PRIO == 4 ? 3 : 0);      // 4: the load phase at top priority; 5: the compute phase instead
-#elif RC_RR_PRIO
-    {
-#if RC_RR_PRIO == 1
-        const int pr = blockIdx.x & 3;
-#elif RC_RR_PRIO == 2
-        const int pr = (blockIdx.x >> 3) & 3;
-#else
-        const int pr = (__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (16 << 6) | 4)) & 3;   // HW_ID bits [19:16]: thread-group slot on the CU
-#endif
-        if (pr == 1) __builtin_amdgcn_s_setprio(1);
-        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
-    }
-#endif
-
-    // ---- every global load of the block, issued together
-#if RC_RR_ABL == 2
-    if (a.w < 0)        // timing-only build: no global loads (the compute runs on whatever LDS holds)
-#endif
-    {
-        const int wave_base = tid & ~63;
-#pragma unroll
-        for (int q = 0; q < NWL; q++) {
-            int idx = tid + q * NT;
-            int wy = idx / WP, wx = idx - wy * WP;
-            int gx = ox + wx, gy = oy + wy;
-            bool ok = idx < WN && (unsigned)gx < (unsigned)w && (unsigned)gy < (unsigned)h;
-            size_t p = ok ? (size_t)gy * w + gx : 0;      // out-of-image texels are never read
-            if (q * NT + wave_base < WN) {
-                rc_glds16(RA1 + p, LA + (q * NT + wave_base));
-                rc_glds4(RB1 + p, LB + (q * NT + wave_base));
-            }
-        }
-    }
-    float4 A0[NIT];
-    float B0[NIT];
-#pragma unroll
-    for (int q = 0; q < NIT; q++) {
-        size_t p0 = (size_t)gys[q] * w + gxo;
-#if RC_RR_ABL == 2
-        A0[q] = make_float4(1.f + q, 0.5f * x, 0.25f, 0.125f * grp);
-        B0[q] = 0.1f * q;
-        (void)p0;
-#else
-        A0[q] = RA0[p0];
-        B0[q] = RB0[p0];
-#endif
-    }
-    float dx[NIT], dy[NIT];
-    rc_rr_flow_in<IN_MODE, NIT, MW, MH>(a, fin, tx0, ty0, gxo, gys, dx, dy);
-    __syncthreads();      // (drains the LDS-DMA)
-#if RC_RR_PRIO == 4 || RC_RR_PRIO == 5
-    __builtin_amdgcn_s_setprio(RC_RR_PRIO == 4 ? 0 : 3);
-#endif
-#if RC_RR_ABL == 1
-    if (a.w > 0) {        // timing-only build: the loads alone
-        float acc = LB[tid] + dx[0] + dy[NIT - 1];
-#pragma unroll
-        for (int q = 0; q < NIT; q++) acc += A0[q].x + A0[q].w + B0[q];
-        if (acc == 12345.678f) *(float*)fout = acc;
-        return;
-    }
-#endif
-
-    // ---- M0 on the whole grid, in registers
-    float m[NIT][5];
-#pragma unroll
-    for (int q = 0; q < NIT; q++) {
-        RcGather g;
-        rc_gather_window<WW, WH, WP>(g, LA, LB, ox, oy, RA1, RB1, gxo, gys[q], dx[q], dy[q], w, h);
-        RcM5 v = rc_matrices_reg(A0[q], B0[q], g, dx[q], dy[q], gxo, gys[q], w, h, !interior);
-        m[q][0] = v.m0; m[q][1] = v.m1; m[q][2] = v.m2; m[q][3] = v.m3; m[q][4] = v.m4;
-    }
-    rc_rr_exchange<NIT, MW>(m, XR, grp, x);
-    __syncthreads();
-
-    // ---- flow1 (meaningful on the grid minus its outer ring), then M1 in place of M0
-    {
-        float2 f1[NIT];
-        rc_rr_flows<GAUSS_, NIT, MW, NG>(m, XR, grp, x, a.win, f1);
-#pragma unroll
-        for (int q = 0; q < NIT; q++) {
-            RcGather g;
-            rc_gather_window<WW, WH, WP>(g, LA, LB, ox, oy, RA1, RB1, gxo, gys[q], f1[q].x, f1[q].y, w, h);
-            RcM5 v = rc_matrices_reg(A0[q], B0[q], g, f1[q].x, f1[q].y, gxo, gys[q], w, h, !interior);
-            m[q][0] = v.m0; m[q][1] = v.m1; m[q][2] = v.m2; m[q][3] = v.m3; m[q][4] = v.m4;
-        }
-    }
-    __syncthreads();      // the exchange rows and the R1 window have been read by everyone
-    if (!interior) {
-        // A grid position outside the image stands for the border pixel it replicates (the
-        // window's replicate border): take that pixel's M1.  Block-uniform branch.
-#pragma unroll
-        for (int q = 0; q < NIT; q++)
-#pragma unroll
-            for (int c = 0; c < 5; c++) Ms[c * PLANE + (ly0 + q) * MP + x] = m[q][c];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < NIT; q++) {
-            const int py = ty0 - 2 + ly0 + q;
-            if ((unsigned)px >= (unsigned)w || (unsigned)py >= (unsigned)h) {
-                const int cx = gxo - (tx0 - 2), cy = gys[q] - (ty0 - 2);
-#pragma unroll
-                for (int c = 0; c < 5; c++) m[q][c] = Ms[c * PLANE + cy * MP + cx];
-            }
-        }
-    }
-    rc_rr_exchange<NIT, MW>(m, XR, grp, x);
-    __syncthreads();
-
-    // ---- flow2 on the tile
-    {
-        float2 f2[NIT];
-        rc_rr_flows<GAUSS_, NIT, MW, NG>(m, XR, grp, x, a.win, f2);
-        if (x >= 2 && x < MW - 2 && px < w) {
-#pragma unroll
-            for (int q = 0; q < NIT; q++) {
-                const int ly = ly0 + q, py = ty0 - 2 + ly;
-                if (ly >= 2 && ly < MH - 2 && py < h)
-                    *(float2*)(fout + (size_t)py * a.fout_step + (size_t)px * 8) = f2[q];
-            }
-        }
-    }
-}
-
-template <int IN_MODE, int G, int NIT, int D, int MINB, int MW = 32, int NG = 8>
-static void launch_rr_t(RcIterArgs a, int pairs, hipStream_t s) {
-    constexpr int MH = NG * NIT, TW = MW - 4, TH = MH - 4;
-    a.tw = TW; a.th = TH;
-    a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
-    constexpr int WN = (MW + 2 * D + RC_RR_WPAD) * (MH + 2 * D), WNP = (WN + 63) & ~63;
-    size_t lds = sizeof(float) * (5 * WNP + NG * 2 * 5 * MW);
-    if (const char* pad = getenv("RC_RR_LDS_PAD_KB")) lds += (size_t)atoi(pad) * 1024;      // occupancy experiment: fewer blocks per CU
-    RC_ALLOW_LDS((k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB, MW, NG>), lds);
-    hipLaunchKernelGGL((k_flow_iter2_rr<IN_MODE, G, NIT, D, MINB, MW, NG>), dim3(a.tiles_x * a.tiles_y, pairs, 1), dim3(NG * MW), lds, s, a);
-}
-
 
 // ---- k_flow_iter2_rrc: the register-row kernel walking a CHAIN of consecutive frame pairs on one tile.
 // Pair z + 1's "previous" expansion R0 is pair z's "next" expansion R1 (the reference's u_f1.copyTo(u_f2),
@@ -1493,10 +1034,9 @@ static void launch_rr_t(RcIterArgs a, int pairs, hipStream_t s) {
 // is issued as soon as the window of pair z is dead, ahead of pair z's last window sums, solve and stores.
 // The DMA goes out from inline asm and the barriers inside the loop wait for LDS traffic only (the compiler
 // would otherwise drain the outstanding DMA before every LDS read); one s_waitcnt vmcnt(0) per pair, at the
-// top of the loop, closes it.  Same arithmetic per pixel as k_flow_iter2_rr: bit-identical.
-__device__ __forceinline__ void rc_glds16_asm(const void* g, const void* lds_wave_base);
-__device__ __forceinline__ void rc_glds4_asm(const void* g, const void* lds_wave_base);
-__device__ __forceinline__ void rc_lds_barrier();
+// top of the loop, closes it.  A launch of independent pairs is the same kernel with chains of one.
+// barrier of the compute phase: LDS traffic only
+__device__ __forceinline__ void rc_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void rc_all_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // LDS-DMA with a wave-uniform base in SGPRs, a 32-bit byte offset per lane and the wave's LDS destination as a
@@ -1766,7 +1306,7 @@ static void launch_rrc_t(RcIterArgs a, const RcChainPlan& cp, int pairs, hipStre
 // is shortened until the launch still has ~8 blocks per block slot of the GPU (1024 = 256 CUs x 4).
 static void rc_chain_plan(const RcIterArgs& a, int pairs, long long tiles, RcChainPlan& cp) {
     cp.ngroups = 0;
-    const bool chainable = a.chain > 1 && pairs > 1 && a.addr32 && (a.slot0 + a.zstep) % a.nslots == a.slot1 % a.nslots;
+    const bool chainable = a.chain > 1 && pairs > 1 && (a.slot0 + a.zstep) % a.nslots == a.slot1 % a.nslots;
     if (!chainable) return;
     int chain = a.chain;
     if (!(a.ablate & RC_ABL_FORCE_CHAIN))
@@ -1783,429 +1323,26 @@ static void rc_chain_plan(const RcIterArgs& a, int pairs, long long tiles, RcCha
     cp.ngroups = n;
 }
 
-// ---- k_flow_iter2_db: the register-row kernel with its loads taken out of the block's critical path.
-// A block of 512 threads (NG = 16 groups of NIT = 2 rows) walks `chain` consecutive tiles of one pair and keeps
-// TWO R1 windows in LDS: while tile i is computed from one, the LDS-DMA of tile i + 1 fills the other, and the
-// thread's R0 texels and coarse-flow texels of tile i + 1 wait in registers.  The DMA is issued from inline asm
-// (the compiler would otherwise order every LDS read behind the outstanding DMA), the barriers inside the
-// compute phase wait for LDS traffic only (`__syncthreads()` would wait for the prefetch as well), and one
-// `s_waitcnt vmcnt(0)` at the top of a tile closes the prefetch issued a whole tile earlier.
-// Same arithmetic, same order of operations per pixel: bit-identical to k_flow_iter2_rr.
-__device__ __forceinline__ void rc_glds16_asm(const void* g, const void* lds_wave_base) {
-    const uint32_t b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(b) : "memory");
-}
-__device__ __forceinline__ void rc_glds4_asm(const void* g, const void* lds_wave_base) {
-    const uint32_t b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(b) : "memory");
-}
-// barrier of the compute phase: LDS traffic only
-__device__ __forceinline__ void rc_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <int NIT>
-struct RcDbPre {
-    float4 A0[NIT];
-    float B0[NIT];
-    float2 d[NIT];            // IN_MODE 1
-    float2 rq[4 * NIT];       // IN_MODE 2: raw coarse texels, ONE load pattern for every path (a per-path pattern would
-                              // merge the paths' loaded registers at the join, and that merge waits for the loads)
-};
-
-// coarse-flow path of a tile (block-uniform): 0 = shared coarse rows, 16-byte loads; 1 = shared coarse rows; 2 = general
-template <int NIT, int MW, int MH>
-__device__ __forceinline__ int rc_db_coarse_mode(const RcIterArgs& a, int tx0, int ty0) {
-    if ((NIT % 2 == 0) && a.up_exact2 && ty0 - 2 >= 0 && ty0 - 2 + MH <= a.h) {
-        const bool cols_plain = tx0 - 2 >= 1 && tx0 - 2 + MW <= a.w && ((tx0 - 2 + MW - 2) >> 1) + 1 <= a.fin_w - 1;
-        return cols_plain ? 0 : 1;
-    }
-    return 2;
-}
-
-// PIECES: bit q (q < 3) = chunk q of the window's LDS-DMA, bit 3 = the R0 texels, bit 4 = the incoming-flow texels.  The
-// kernel issues the pieces at different points of the compute phase: a burst of vector-memory instructions stalls
-// the issuing wave until the memory pipeline has accepted them, a trickle does not.
-template <int IN_MODE, int NIT, int D, int MW, int NG, int PIECES = 31>
-__device__ __forceinline__ void rc_db_issue(const RcIterArgs& a, int t, float* Wb, RcDbPre<NIT>& P, const float4* __restrict__ RA0,
-                                            const float* __restrict__ RB0, const float4* __restrict__ RA1,
-                                            const float* __restrict__ RB1, const float2* __restrict__ fin) {
-    constexpr int NT = NG * MW, MH = NG * NIT, TW = MW - 4, TH = MH - 4;
-    constexpr int WW = MW + 2 * D, WH = MH + 2 * D, WP = WW, WN = WP * WH, NWL = (WN + NT - 1) / NT;
-    constexpr int WNP = (WN + 63) & ~63;
-    const int tid = threadIdx.x, w = a.w, h = a.h;
-    const int tx0 = (t % a.tiles_x) * TW, ty0 = (t / a.tiles_x) * TH;
-    const int ox = tx0 - 2 - D, oy = ty0 - 2 - D;
-    float4* LA = (float4*)Wb;
-    float* LB = Wb + 4 * WNP;
-    const int wave_base = tid & ~63;
-    static_assert(NWL <= 3, "three DMA pieces");
-#pragma unroll
-    for (int q = 0; q < NWL; q++) {
-        if (!(PIECES & (1 << q))) continue;
-        int idx = tid + q * NT;
-        int wy = idx / WP, wx = idx - wy * WP;
-        int gx = ox + wx, gy = oy + wy;
-        bool ok = idx < WN && (unsigned)gx < (unsigned)w && (unsigned)gy < (unsigned)h;
-        size_t p = ok ? (size_t)gy * w + gx : 0;      // out-of-image texels are never read
-        if (q * NT + wave_base < WN) {
-            rc_glds16_asm(RA1 + p, LA + (q * NT + wave_base));
-            rc_glds4_asm(RB1 + p, LB + (q * NT + wave_base));
-        }
-    }
-    if (!(PIECES & 24)) return;
-    const int x = tid & (MW - 1), ly0 = (tid / MW) * NIT;
-    const int gxo = rc_clampi(tx0 - 2 + x, 0, w - 1);
-    int gys[NIT];
-#pragma unroll
-    for (int q = 0; q < NIT; q++) gys[q] = rc_clampi(ty0 - 2 + ly0 + q, 0, h - 1);
-    if (PIECES & 8) {
-#pragma unroll
-        for (int q = 0; q < NIT; q++) {
-            size_t p0 = (size_t)gys[q] * w + gxo;
-            P.A0[q] = RA0[p0];
-            P.B0[q] = RB0[p0];
-        }
-    }
-    if (!(PIECES & 16)) return;
-    if constexpr (IN_MODE == 1) {
-#pragma unroll
-        for (int q = 0; q < NIT; q++) P.d[q] = fin[(size_t)gys[q] * w + gxo];
-    } else if constexpr (IN_MODE == 2) {
-        static_assert(NIT == 2, "slot layout below is written for two rows per thread");
-        const bool shared_rows = rc_db_coarse_mode<NIT, MW, MH>(a, tx0, ty0) < 2;
-        float ax;
-        int sx;
-        if (a.up_exact2) {
-            sx = (gxo - 1) >> 1;
-            if (sx < 0) sx = 0;
-            if (sx >= a.fin_w - 1) sx = a.fin_w - 1;
-        } else {
-            sx = rc_src_x(gxo, a.up_scale_x, a.fin_w, ax);
-        }
-        const int sx1 = min(sx + 1, a.fin_w - 1);
-        int rows[4];        // shared coarse rows: rb, rb + 1, rb + 2 (, rb + 2); general: row q's two source rows
-        if (shared_rows) {
-            const int rb = (gys[0] - 1) >> 1;
-#pragma unroll
-            for (int j = 0; j < 4; j++) rows[j] = rc_clampi(rb + (j < 3 ? j : 2), 0, a.fin_h - 1);
-        } else {
-#pragma unroll
-            for (int q = 0; q < NIT; q++) {
-                float ay;
-                const int sy = a.up_exact2 ? (gys[q] - 1) >> 1 : rc_src_y(gys[q], a.up_scale_y, ay);
-                rows[2 * q] = rc_clampi(sy, 0, a.fin_h - 1);
-                rows[2 * q + 1] = rc_clampi(sy + 1, 0, a.fin_h - 1);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float2* S = fin + (size_t)rows[j] * a.fin_w;
-            P.rq[2 * j] = S[sx];
-            P.rq[2 * j + 1] = S[sx1];
-        }
-    }
-}
-
-// the tile's incoming flow from the prefetched texels (the arithmetic of k_flow_iter2_rr's three paths)
-template <int IN_MODE, int NIT, int MW, int MH>
-__device__ __forceinline__ void rc_db_flow_in(const RcIterArgs& a, const RcDbPre<NIT>& P, int tx0, int ty0, int gxo,
-                                              const int (&gys)[NIT], float (&dx)[NIT], float (&dy)[NIT]) {
-    if constexpr (IN_MODE == 0) {
-#pragma unroll
-        for (int q = 0; q < NIT; q++) dx[q] = dy[q] = 0.f;
-    } else if constexpr (IN_MODE == 1) {
-#pragma unroll
-        for (int q = 0; q < NIT; q++) { dx[q] = P.d[q].x; dy[q] = P.d[q].y; }
-    } else {
-        const bool shared_rows = rc_db_coarse_mode<NIT, MW, MH>(a, tx0, ty0) < 2;
-        if (shared_rows) {
-            constexpr int NR = NIT / 2 + 2;
-            int sx = (gxo - 1) >> 1;
-            float ax = (gxo & 1) ? 0.25f : 0.75f;
-            if (sx < 0) { ax = 0.f; sx = 0; }
-            if (sx >= a.fin_w - 1) { ax = 0.f; sx = a.fin_w - 1; }
-            const float a0 = 1.f - ax, a1 = ax;
-            float hx[NR], hy[NR];
-#pragma unroll
-            for (int j = 0; j < NR; j++) {
-                hx[j] = P.rq[2 * j].x * a0 + P.rq[2 * j + 1].x * a1;
-                hy[j] = P.rq[2 * j].y * a0 + P.rq[2 * j + 1].y * a1;
-            }
-#pragma unroll
-            for (int q = 0; q < NIT; q++) {
-                const int j0 = (q + 1) >> 1;
-                const float b1 = (q & 1) ? 0.25f : 0.75f, b0 = 1.f - b1;
-                dx[q] = (hx[j0] * b0 + hx[j0 + 1] * b1) * a.up_mul;
-                dy[q] = (hy[j0] * b0 + hy[j0 + 1] * b1) * a.up_mul;
-            }
-        } else {
-            float ax, ay[NIT];
-            if (a.up_exact2) {
-                int sx = (gxo - 1) >> 1;
-                ax = (gxo & 1) ? 0.25f : 0.75f;
-                if (sx < 0) ax = 0.f;
-                if (sx >= a.fin_w - 1) ax = 0.f;
-#pragma unroll
-                for (int q = 0; q < NIT; q++) ay[q] = (gys[q] & 1) ? 0.25f : 0.75f;
-            } else {
-                (void)rc_src_x(gxo, a.up_scale_x, a.fin_w, ax);
-#pragma unroll
-                for (int q = 0; q < NIT; q++) (void)rc_src_y(gys[q], a.up_scale_y, ay[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < NIT; q++) {
-                const float2 p00 = P.rq[4 * q], p01 = P.rq[4 * q + 1], p10 = P.rq[4 * q + 2], p11 = P.rq[4 * q + 3];
-                float a0 = 1.f - ax, a1 = ax, b0 = 1.f - ay[q], b1 = ay[q];
-                float r0x = p00.x * a0 + p01.x * a1, r1x = p10.x * a0 + p11.x * a1;
-                float r0y = p00.y * a0 + p01.y * a1, r1y = p10.y * a0 + p11.y * a1;
-                dx[q] = (r0x * b0 + r1x * b1) * a.up_mul;
-                dy[q] = (r0y * b0 + r1y * b1) * a.up_mul;
-            }
-        }
-    }
-}
-
-// FarnebackUpdateMatrices of one grid pixel in the compute phase of k_flow_iter2_db.  The common case -- every
-// lane's 2x2 footprint inside the LDS window -- must not contain a single vector-memory instruction: the
-// memory counter is in order, so waiting for ANY load there would wait for the next tile's prefetch.  A wave with
-// a lane outside the window takes the mixed gather of k_flow_iter2_rr instead and finishes its loads inside that
-// branch (the empty asm statements consume the loaded registers, so no pending load reaches the join).
-template <int WW, int WH, int WP>
-__device__ __forceinline__ RcM5 rc_db_matrices(const float4* LA, const float* LB, int ox, int oy,
-                                               const float4* __restrict__ RA1, const float* __restrict__ RB1,
-                                               const float4 A0, const float B0, int gx, int gy, float dx, float dy,
-                                               int w, int h, bool border) {
-    RcGather g;
-    const float fx = gx + dx, fy = gy + dy;
-    const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
-    const bool inside = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
-    const int wx = x1 - ox, wy = y1 - oy;
-    const bool inwin = (unsigned)wx < (unsigned)(WW - 1) && (unsigned)wy < (unsigned)(WH - 1);
-    if (__builtin_amdgcn_ballot_w64(inside && !inwin) != 0) {
-        rc_gather_window<WW, WH, WP>(g, LA, LB, ox, oy, RA1, RB1, gx, gy, dx, dy, w, h);
-#define RC_USE4(v) asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w))
-        RC_USE4(g.q00); RC_USE4(g.q01); RC_USE4(g.q10); RC_USE4(g.q11);
-#undef RC_USE4
-        asm volatile("" : "+v"(g.e00), "+v"(g.e01), "+v"(g.e10), "+v"(g.e11));
-    } else {
-        g.fx = fx - x1;
-        g.fy = fy - y1;
-        g.inside = inside;
-        const int i = inside ? wy * WP + wx : 0;        // (a footprint outside the image is never used)
-        g.q00 = LA[i]; g.q01 = LA[i + 1]; g.q10 = LA[i + WP]; g.q11 = LA[i + WP + 1];
-        g.e00 = LB[i]; g.e01 = LB[i + 1]; g.e10 = LB[i + WP]; g.e11 = LB[i + WP + 1];
-    }
-    return rc_matrices_reg(A0, B0, g, dx, dy, gx, gy, w, h, border);
-}
-
-template <int IN_MODE, int GAUSS_, int NIT, int D, int MW, int NG>
-__global__ __launch_bounds__(NG * MW, 4) void k_flow_iter2_db(RcIterArgs a, int chain, int nchains) {
-    constexpr int MH = NG * NIT, TW = MW - 4, TH = MH - 4;
-    constexpr int WW = MW + 2 * D, WH = MH + 2 * D, WP = WW, WN = WP * WH;
-    constexpr int WNP = (WN + 63) & ~63;
-    constexpr int MP = MW + 1, PLANE = MH * MP;
-    static_assert(5 * PLANE <= 5 * WNP, "border-block M1 planes alias the R1 window");
-    extern __shared__ __align__(16) float smf[];
-    float* XR = smf + 10 * WNP;             // [NG][2][5][MW] first / last row of every group
-    const int tid = threadIdx.x;
-    const int z = blockIdx.y;
-    const int c = a.xcd_remap ? rc_xcd_remap(blockIdx.x, nchains) : (int)blockIdx.x;
-    const int ntiles = a.tiles_x * a.tiles_y;
-    const int tbeg = c * chain, tend = min(tbeg + chain, ntiles);
-    const int w = a.w, h = a.h;
-    const size_t s0 = (size_t)((a.slot0 + z * a.zstep) % a.nslots) * a.R_slot_stride;
-    const size_t s1 = (size_t)((a.slot1 + z * a.zstep) % a.nslots) * a.R_slot_stride;
-    const float4* __restrict__ RA0 = a.RA + s0;  const float* __restrict__ RB0 = a.RB + s0;
-    const float4* __restrict__ RA1 = a.RA + s1;  const float* __restrict__ RB1 = a.RB + s1;
-    const float2* __restrict__ fin = a.fin + (size_t)z * a.fin_pair_stride;
-    char* fout = a.fout + (size_t)z * a.fout_pair_stride;
-    const int x = tid & (MW - 1), grp = tid / MW, ly0 = grp * NIT;
-
-    RcDbPre<NIT> P;
-#if RC_DB_ABL == 1
-#pragma unroll
-    for (int q = 0; q < NIT; q++) { P.A0[q] = make_float4(1.f + q, 0.5f * x, 0.25f, 0.125f * grp); P.B0[q] = 0.1f * q; P.d[q] = make_float2(0.1f, 0.2f); }
-#pragma unroll
-    for (int j = 0; j < 4 * NIT; j++) P.rq[j] = make_float2(0.1f * j, 0.2f);
-    if (a.w < 0)
-#endif
-    rc_db_issue<IN_MODE, NIT, D, MW, NG>(a, tbeg, smf, P, RA0, RB0, RA1, RB1, fin);
-    for (int t = tbeg; t < tend; t++) {
-        const int par = (t - tbeg) & 1;
-        float* Wc = smf + (par ? 5 * WNP : 0);
-        float* Wn = smf + (par ? 0 : 5 * WNP);
-        const float4* LA = (const float4*)Wc;
-        const float* LB = Wc + 4 * WNP;
-        float* Ms = Wc;                         // border blocks only: [5][MH][MP], after the window is dead
-        const int tx0 = (t % a.tiles_x) * TW, ty0 = (t / a.tiles_x) * TH;
-        const int ox = tx0 - 2 - D, oy = ty0 - 2 - D;
-        const int px = tx0 - 2 + x;
-        const int gxo = rc_clampi(px, 0, w - 1);
-        int gys[NIT];
-#pragma unroll
-        for (int q = 0; q < NIT; q++) gys[q] = rc_clampi(ty0 - 2 + ly0 + q, 0, h - 1);
-        const bool interior = tx0 - 2 >= 5 && tx0 - 2 + MW <= w - 5 && ty0 - 2 >= 5 && ty0 - 2 + MH <= h - 5;
-
-        // tile t's window, R0 and coarse texels have been in flight since the previous tile's compute phase
-#if RC_DB_ABL == 3
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-        // every prefetched register counts as consumed here (a path that leaves one unread would make the next
-        // prefetch wait before overwriting it -- behind its own DMA)
-#pragma unroll
-        for (int q = 0; q < NIT; q++) {
-            asm volatile("" : "+v"(P.A0[q].x), "+v"(P.A0[q].y), "+v"(P.A0[q].z), "+v"(P.A0[q].w), "+v"(P.B0[q]));
-            if constexpr (IN_MODE == 1) asm volatile("" : "+v"(P.d[q].x), "+v"(P.d[q].y));
-        }
-        if constexpr (IN_MODE == 2) {
-#pragma unroll
-            for (int j = 0; j < 4 * NIT; j++) asm volatile("" : "+v"(P.rq[j].x), "+v"(P.rq[j].y));
-        }
-        float4 A0[NIT];
-        float B0[NIT];
-#pragma unroll
-        for (int q = 0; q < NIT; q++) { A0[q] = P.A0[q]; B0[q] = P.B0[q]; }
-        float dx[NIT], dy[NIT];
-        rc_db_flow_in<IN_MODE, NIT, MW, MH>(a, P, tx0, ty0, gxo, gys, dx, dy);
-#if RC_DB_ABL == 1
-        const bool nxt = a.w < 0;
-#else
-        const bool nxt = t + 1 < tend;
-#endif
-#define RC_DB_PIECE(mask)                                                                                 \
-    do {                                                                                                  \
-        if (nxt) rc_db_issue<IN_MODE, NIT, D, MW, NG, (mask)>(a, t + 1, Wn, P, RA0, RB0, RA1, RB1, fin);   \
-        asm volatile("" ::: "memory");                                                                    \
-    } while (0)
-#if RC_DB_SPREAD
-        RC_DB_PIECE(1);
-#else
-        RC_DB_PIECE(31);
-#endif
-
-#if RC_DB_ABL == 2
-        if (a.w > 0) {          // the loads alone
-            RC_DB_PIECE(30);
-            float acc = LB[tid] + dx[0] + dy[NIT - 1];
-#pragma unroll
-            for (int q = 0; q < NIT; q++) acc += A0[q].x + A0[q].w + B0[q];
-            if (acc == 12345.678f) *(float*)fout = acc;
-            continue;
-        }
-#endif
-        // ---- M0 on the whole grid, in registers
-        float m[NIT][5];
-#pragma unroll
-        for (int q = 0; q < NIT; q++) {
-            RcM5 v = rc_db_matrices<WW, WH, WP>(LA, LB, ox, oy, RA1, RB1, A0[q], B0[q], gxo, gys[q], dx[q], dy[q], w, h, !interior);
-            m[q][0] = v.m0; m[q][1] = v.m1; m[q][2] = v.m2; m[q][3] = v.m3; m[q][4] = v.m4;
-#if RC_DB_SPREAD
-            if (q == 0) RC_DB_PIECE(2);
-#endif
-        }
-#if RC_DB_SPREAD
-        RC_DB_PIECE(4);
-#endif
-        rc_rr_exchange<NIT, MW>(m, XR, grp, x);
-        rc_lds_barrier();
-
-        // ---- flow1, then M1 in place of M0
-        {
-            float2 f1[NIT];
-            rc_rr_flows<GAUSS_, NIT, MW, NG>(m, XR, grp, x, a.win, f1);
-#if RC_DB_SPREAD
-            RC_DB_PIECE(8);
-#endif
-#pragma unroll
-            for (int q = 0; q < NIT; q++) {
-                RcM5 v = rc_db_matrices<WW, WH, WP>(LA, LB, ox, oy, RA1, RB1, A0[q], B0[q], gxo, gys[q], f1[q].x, f1[q].y, w, h, !interior);
-                m[q][0] = v.m0; m[q][1] = v.m1; m[q][2] = v.m2; m[q][3] = v.m3; m[q][4] = v.m4;
-            }
-        }
-#if RC_DB_SPREAD
-        RC_DB_PIECE(16);
-#endif
-        rc_lds_barrier();      // the exchange rows and the R1 window have been read by everyone
-        if (!interior) {
-#pragma unroll
-            for (int q = 0; q < NIT; q++)
-#pragma unroll
-                for (int cc = 0; cc < 5; cc++) Ms[cc * PLANE + (ly0 + q) * MP + x] = m[q][cc];
-            rc_lds_barrier();
-#pragma unroll
-            for (int q = 0; q < NIT; q++) {
-                const int py = ty0 - 2 + ly0 + q;
-                if ((unsigned)px >= (unsigned)w || (unsigned)py >= (unsigned)h) {
-                    const int cx = gxo - (tx0 - 2), cy = gys[q] - (ty0 - 2);
-#pragma unroll
-                    for (int cc = 0; cc < 5; cc++) m[q][cc] = Ms[cc * PLANE + cy * MP + cx];
-                }
-            }
-        }
-        rc_rr_exchange<NIT, MW>(m, XR, grp, x);
-        rc_lds_barrier();
-
-        // ---- flow2 on the tile
-        {
-            float2 f2[NIT];
-            rc_rr_flows<GAUSS_, NIT, MW, NG>(m, XR, grp, x, a.win, f2);
-            if (x >= 2 && x < MW - 2 && px < w) {
-#pragma unroll
-                for (int q = 0; q < NIT; q++) {
-                    const int ly = ly0 + q, py = ty0 - 2 + ly;
-                    if (ly >= 2 && ly < MH - 2 && py < h)
-                        *(float2*)(fout + (size_t)py * a.fout_step + (size_t)px * 8) = f2[q];
-                }
-            }
-        }
-    }
-}
-
-template <int IN_MODE, int G, int NIT = 2, int D = 3, int MW = 32, int NG = 16>
-static void launch_db_t(RcIterArgs a, int pairs, hipStream_t s) {
-    constexpr int MH = NG * NIT, TW = MW - 4, TH = MH - 4;
-    a.tw = TW; a.th = TH;
-    a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
-    constexpr int WN = (MW + 2 * D) * (MH + 2 * D), WNP = (WN + 63) & ~63;
-    const size_t lds = sizeof(float) * (10 * WNP + NG * 2 * 5 * MW);
-    int chain = 8;
-    if (const char* e = getenv("RC_DB_CHAIN")) chain = atoi(e) > 0 ? atoi(e) : 8;
-    const int ntiles = a.tiles_x * a.tiles_y, nchains = (ntiles + chain - 1) / chain;
-    RC_ALLOW_LDS((k_flow_iter2_db<IN_MODE, G, NIT, D, MW, NG>), lds);
-    hipLaunchKernelGGL((k_flow_iter2_db<IN_MODE, G, NIT, D, MW, NG>), dim3(nchains, pairs, 1), dim3(NG * MW), lds, s, a, chain, nchains);
-}
-
 template <int IN_MODE, int G>
 static void launch_w3x2(RcIterArgs a, int pairs, hipStream_t s) {
-    if (a.ablate & RC_ABL_W3X2_LDS_M) launch_w3x2_t<IN_MODE, G, 32, 16, 256, 4>(a, pairs, s);   // LDS-resident M (first form)
-    else if (a.ablate & RC_ABL_RR_28X20) launch_rr_t<IN_MODE, G, 3, 4, 5>(a, pairs, s);     // 28x20 tile, 5 blocks per CU
-    else if (a.ablate & RC_ABL_RR_28X12) launch_rr_t<IN_MODE, G, 2, 4, 6>(a, pairs, s);     // 28x12 tile, 6 blocks per CU
-    else if (a.ablate & RC_ABL_RR_60X28) launch_rr_t<IN_MODE, G, 4, 3, 2, 64>(a, pairs, s);  // 60x28 tile, 512 threads, 2 blocks per CU
-    else if (a.ablate & RC_ABL_RR_DB) launch_db_t<IN_MODE, G>(a, pairs, s);                  // double-buffered window, 512 threads, tile chains
-    else if (a.ablate & RC_ABL_RR_512T) launch_rr_t<IN_MODE, G, 2, 3, 4, 32, 16>(a, pairs, s);  // 28x28 tile, 512 threads x 2 rows
-    else if (a.ablate & RC_ABL_RR_512T_8W) launch_rr_t<IN_MODE, G, 2, 3, 8, 32, 16>(a, pairs, s); // same, registers capped for 8 waves per SIMD
-    else {
-        // A launch of fewer blocks than the GPU holds at once (1024 = 256 CUs x 4) lasts one block's
-        // lifetime: shorter tiles then finish sooner (frame-at-a-time calls, coarse scales).  Same bits.
-        const long long tiles = (long long)((a.w + 27) / 28) * ((a.h + 27) / 28), blocks = tiles * pairs;
-        // consecutive pairs of one stream (pair z + 1's previous frame is pair z's next frame): tile chains
-        RcChainPlan cp;
-        rc_chain_plan(a, pairs, tiles, cp);
-        if (!a.addr32) launch_rr_t<IN_MODE, G, 4, RC_RR_D, 4>(a, pairs, s);             // (64-bit offsets: the first form of the kernel)
-        else if (cp.ngroups) launch_rrc_t<IN_MODE, G, 4, RC_RR_D, 4>(a, cp, pairs, s);  // 28x28 tile, chains of pairs
-        else if (blocks < 512) launch_rrc_t<IN_MODE, G, 2, 4, 6>(a, cp, pairs, s);      // 28x12 tile
-        else if (blocks < 1024) launch_rrc_t<IN_MODE, G, 3, 4, 5>(a, cp, pairs, s);     // 28x20 tile
-        else launch_rrc_t<IN_MODE, G, 4, RC_RR_D, 4>(a, cp, pairs, s);                  // 28x28 tile, 4 blocks per CU
-    }
+    // A launch of fewer blocks than the GPU holds at once (1024 = 256 CUs x 4) lasts one block's lifetime:
+    // shorter tiles then finish sooner (frame-at-a-time calls, coarse scales).  Same bits.
+    const long long tiles = (long long)((a.w + 27) / 28) * ((a.h + 27) / 28), blocks = tiles * pairs;
+    // consecutive pairs of one stream (pair z + 1's previous frame is pair z's next frame): tile chains
+    RcChainPlan cp;
+    rc_chain_plan(a, pairs, tiles, cp);
+    if (cp.ngroups) launch_rrc_t<IN_MODE, G, 4, RC_RR_D, 4>(a, cp, pairs, s);       // 28x28 tile, chains of pairs
+    else if (blocks < 512) launch_rrc_t<IN_MODE, G, 2, 4, 6>(a, cp, pairs, s);      // 28x12 tile, 6 blocks per CU
+    else if (blocks < 1024) launch_rrc_t<IN_MODE, G, 3, 4, 5>(a, cp, pairs, s);     // 28x20 tile, 5 blocks per CU
+    else launch_rrc_t<IN_MODE, G, 4, RC_RR_D, 4>(a, cp, pairs, s);                  // 28x28 tile, 4 blocks per CU
 }
 
-int rc_flow_iter_can_fuse2(const RcIterArgs& a) { return a.win.m == 1 && a.solve; }
+// (the fused kernel addresses with 32-bit offsets: frames or caller strides beyond 4 GB take one launch per iteration)
+int rc_flow_iter_can_fuse2(const RcIterArgs& a) { return a.win.m == 1 && a.solve && a.addr32; }
 
 // How many of the launch's `pairs` read their previous-frame coefficients R0 from memory (the head of every tile
 // chain; the others take them from the previous pair's LDS window): the compulsory bytes of the launch as built.
 int rc_flow_iter2_r0_reads(const RcIterArgs& a, int pairs) {
-    if (a.ablate & (RC_ABL_W3X2_LDS_M | RC_ABL_RR_28X20 | RC_ABL_RR_28X12 | RC_ABL_RR_60X28 | RC_ABL_RR_DB | RC_ABL_RR_512T | RC_ABL_RR_512T_8W)) return pairs;
     RcChainPlan cp;
     rc_chain_plan(a, pairs, (long long)((a.w + 27) / 28) * ((a.h + 27) / 28), cp);
     return cp.ngroups ? cp.ngroups : pairs;

@@ -103,16 +103,9 @@ enum RcAblate : int {
     RC_ABL_EXACT_FUSED_M = 16,       // option exact, box windows of winsize 3 / 5: FarnebackUpdateMatrices inside the column scan (measured slower)
     RC_ABL_NO_WINDOW = 4,            // skip window / solve / store
     RC_ABL_EMPTY_BLOCKS = 8,         // launch cost only
-    RC_ABL_RR_DB = 32,               // register-row kernel with two R1 windows: the next tile's loads fly during the compute phase
-    RC_ABL_W3X2_LDS_M = 64,          // fused pair with M in LDS (first form)
-    RC_ABL_RR_28X20 = 128,           // register-row kernel: 28x20 tile, 5 blocks per CU
-    RC_ABL_RR_28X12 = 256,           //   28x12 tile, 6 blocks per CU
-    RC_ABL_RR_60X28 = 512,           //   60x28 tile, 512 threads
-    RC_ABL_RR_512T = 1024,           //   28x28 tile, 512 threads x 2 rows
     RC_ABL_NO_FAST_U8 = 2048,        // expansion at scale 0: per-byte staging instead of dwords + v_perm
     RC_ABL_PYR_STAGED = 4096,        // pyramid: per-pixel / LDS-staged kernels
     RC_ABL_GENERIC_WINDOW = 8192,    // windows 5 / 10 / 20: runtime-sized generic kernel
-    RC_ABL_RR_512T_8W = 16384,       // register-row kernel, 512 threads, registers capped for 8 waves per SIMD
     RC_ABL_BIG_32WIDE = 32768,       // winsize 20 tile kernel: 32-wide tiles
     RC_ABL_TILE_WINDOW = 65536,      // Gaussian winsize 10 / 20: tile kernel even for large launches
     RC_ABL_SWEEP_512T = 131072,      // strip-sweep kernel with 512 threads
@@ -146,7 +139,6 @@ struct RcIterArgs {
     int ablate;               // timing-only ablation bits (0 in production)
     int addr32;               // every offset inside one frame's R planes and one pair's flow field fits 32 bits (set by the level driver)
     int chain;                // option "chain": consecutive pairs a block of the fused winsize-3 kernel walks on its tile (<= 1: none)
-    long long* stamps;        // diagnostic s_memtime stamps (null in production)
     RcWindow win;
 };
 

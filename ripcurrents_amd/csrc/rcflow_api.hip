@@ -784,7 +784,6 @@ static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_
         a.xcd_remap = ctx->xcd_remap;
         a.ablate = ctx->ablate;
         a.chain = ctx->chain;
-        a.stamps = (k == 0) ? (long long*)ctx->stamps : nullptr;
         const float2* cur_in = nullptr;
         int passes = iters > 0 ? iters : 1;
         int nout = 0;   // intermediate buffers written so far at this scale (ping-pong index)
@@ -805,6 +804,9 @@ static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_
                 a.in_mode = 1; a.fin = cur_in; a.fin_pair_stride = n; in_bytes = 8. * n;
             }
             a.solve = iters > 0 ? 1 : 0;
+            // 32-bit offsets inside one frame's coefficient planes and one pair's flow field (the scale's own buffers and,
+            // for the last launch of scale 0, the caller's rows): the condition of the fused two-iteration kernel
+            a.addr32 = n * 16 < (1ull << 32) && (size_t)L.h * (k == 0 ? (out_step > (size_t)L.w * 8 ? out_step : (size_t)L.w * 8) : (size_t)L.w * 8) < (1ull << 32);
             // two iterations per launch whenever two are left and the window allows it
             int fuse = (passes - i >= 2 && ctx->fuse_iters && rc_flow_fast::rc_flow_iter_can_fuse2(a)) ? 2 : 1;
             bool last = (i + fuse == passes);
@@ -816,7 +818,6 @@ static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_
                 a.fout = (char*)dst; a.fout_step = (size_t)L.w * 8; a.fout_pair_stride = n * 8;
                 cur_in = dst;
             }
-            a.addr32 = n * 16 < (1ull << 32) && (size_t)L.h * a.fout_step < (1ull << 32);
             {
                 // SURVEY 8(d) bytes of the stages this launch stands for: the first launch of a scale
                 // carries "init matrices" (8 N_{k+1} + 60 N_k), every iteration but the last 80 N_k

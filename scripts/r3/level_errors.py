@@ -54,6 +54,8 @@ for name, opts in (("exact", dict(exact=1)), ("fast", dict(exact=0)), ("fast+all
     well = det_last > 1e-2
     print("== %s: final max %.3g | well max %.3g p99.9 %.3g | path max %.3g (share %.3f)" %
           (name, err.max(), err[well].max(), np.percentile(err[well], 99.9), err[path].max(), path.mean()))
+    print("   max error over pixels with det_min above: " + "  ".join("%g: %.3g (%.0f %% of px)" % (t, err[det_min > t].max(), 100 * (det_min > t).mean())
+                                                                     for t in (1e-2, 2e-2, 5e-2, 1e-1, 1.0)))
     for k in range(nlev - 1, 0, -1):
         if lv[k] is None:
             continue

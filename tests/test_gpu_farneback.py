@@ -628,28 +628,6 @@ def test_fused_iterations_bit_identical(ctx, p):
     assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("size,params", [((640, 480), dict(levels=2)), ((333, 251), dict(levels=2, flags=256)),
-                                         ((1024, 576), dict(levels=4)), ((700, 500), dict(pyr_scale=0.7, levels=3)),
-                                         ((1920, 1080), dict(levels=2))])
-def test_double_buffered_window_kernel_same_bits(ctx, size, params):
-    """`ablate` 32 = k_flow_iter2_db (two R1 windows per block, the next tile's loads in flight during the compute phase:
-    inline-asm LDS-DMA, counted waits, tile chains).  Measured slower than the production kernel and
-    kept selectable; it must give the same bits, border tiles, upsampling paths and chain ends included."""
-    w, h = size
-    p = dict(pyr_scale=0.5, levels=2, winsize=3, iterations=2, poly_n=15, poly_sigma=1.2, flags=0)
-    p.update(params)
-    clip = torch.as_tensor(synth.surf_clip(w, h, 4, seed=3)).cuda()
-    ctx.set_option("exact", 0)
-    try:
-        a = ctx.farneback_clip(clip, **p).clone()
-        ctx.set_option("ablate", 32)
-        b = ctx.farneback_clip(clip, **p).clone()
-    finally:
-        ctx.set_option("ablate", 0)
-        ctx.set_option("exact", -1)
-    assert torch.equal(a, b)
-
-
 def test_against_committed_golden_fixtures(ctx):
     """tests/golden/*.npz (inputs + oracle outputs, made by tests/golden/make_golden.py)."""
     import os
