@@ -132,6 +132,34 @@ class Pipeline {
         return true;
     }
 
+    // One whole iteration of the frame loop (ripcurrents.cpp:194-479) behind one call: the frame produced into
+    // frameBuffer() is pushed, then streamline_field, the seed streamlines (d_seeds: device, n x (x, y), advanced in
+    // place; may be null), histogram + thresholds, create_flow + create_accumulationbuffer (the frame counter lives on the
+    // device) and the mask's edges run on the resident field (rcflow_frame_loop_step).  Returns false for the call that
+    // primes the stream.  The masks stay on the device: outmaskDevice() / edgesDevice(), or read them back as needed.
+    bool loopStep(double pyr_scale, int levels, int winsize, int iterations, int poly_n, double poly_sigma, int flags,
+                  float dt = 2.f, int streamline_iterations = 1, float* d_seeds = nullptr, int nseeds = 0, float seed_upper = 100.f,
+                  float MID = 0.5f, float LOWER = 0.2f, bool use_graph = false) {
+        if (!d_edges_) hip_check(hipMalloc(&d_edges_, (size_t)w_ * h_), "hipMalloc edges");
+        rc_farneback_params p = {pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags};
+        rc_frame_loop L;
+        std::memset(&L, 0, sizeof(L));
+        L.dt = dt; L.iterations = streamline_iterations;
+        L.d_seeds = d_seeds; L.nseeds = nseeds; L.seed_variant = 3; L.seed_dt = dt; L.seed_iterations = streamline_iterations; L.seed_upper = seed_upper;
+        L.MID = MID; L.LOWER = LOWER;
+        L.d_outmask = (uint8_t*)d_mask_; L.mask_step = (size_t)w_; L.d_edges = (uint8_t*)d_edges_; L.edges_step = (size_t)w_;
+        L.use_graph = use_graph ? 1 : 0;
+        const int rc = rcflow_frame_loop_step(ctx_, 0, &p, &L);
+        check(rc);
+        if (rc == 1) return false;
+        float* d = nullptr;
+        check(rcflow_stream_flow_ptr(ctx_, 0, &d, nullptr, nullptr));
+        flow_src_ = d;
+        return true;
+    }
+    const uint8_t* outmaskDevice() const { return (const uint8_t*)d_mask_; }
+    const uint8_t* edgesDevice() const { return (const uint8_t*)d_edges_; }
+
     void calcOpticalFlowFarneback(const Mat& prev, const Mat& next, Mat& flow, double pyr_scale, int levels,
                                   int winsize, int iterations, int poly_n, double poly_sigma, int flags) {
         if (prev.empty() || next.empty() || prev.rows != next.rows || prev.cols != next.cols ||
@@ -282,7 +310,8 @@ class Pipeline {
         if (d_frames_) (void)hipFree(d_frames_);
         if (d_flow_) (void)hipFree(d_flow_);
         if (d_mask_) (void)hipFree(d_mask_);
-        d_frames_ = d_flow_ = d_mask_ = nullptr;
+        if (d_edges_) (void)hipFree(d_edges_);
+        d_frames_ = d_flow_ = d_mask_ = d_edges_ = nullptr;
         if (ctx_) rcflow_destroy(ctx_);
         ctx_ = nullptr;
     }
@@ -299,7 +328,7 @@ class Pipeline {
     }
     rc_ctx* ctx_ = nullptr;
     int w_, h_;
-    void *d_frames_ = nullptr, *d_flow_ = nullptr, *d_mask_ = nullptr, *d_scratch_ = nullptr;
+    void *d_frames_ = nullptr, *d_flow_ = nullptr, *d_mask_ = nullptr, *d_edges_ = nullptr, *d_scratch_ = nullptr;
     size_t scratch_bytes_ = 0;
     const float* flow_src_ = nullptr;     // the field the analysis calls read: d_flow_ or the stream's resident field
 };

@@ -142,6 +142,36 @@ int main() {
         REQUIRE(memcmp(fl.data(), ref.data(), fl.size() * sizeof(float)) == 0);
         rc_farneback_params prm = {0.5, 2, 3, 2, 15, 1.2, 0};
         REQUIRE(rcflow_push_frame_acquired(pipe.context(), 0, &prm) == RC_ESTATE);       // nothing acquired
+
+        // the whole iteration behind one call (Pipeline::loopStep = rcflow_frame_loop_step), eager and as one hipGraph
+        // launch per frame: the wave mask after three flows equals the one the separate calls produce
+        std::vector<uint8_t> want((size_t)XDIM * YDIM), got((size_t)XDIM * YDIM);
+        rc::Mat mwant(YDIM, XDIM, 1, 1, want.data());
+        REQUIRE(rcflow_analysis_reset(pipe.context(), 0, XDIM, YDIM) == 0);
+        REQUIRE(rcflow_stream_reset(pipe.context(), 0) == 0);
+        int hh[RC_HIST_BINS], hhs = 0, hh2[RC_HIST_DIRECTIONS][RC_HIST_BINS], hhs2[RC_HIST_DIRECTIONS];
+        float hu, hu2[RC_HIST_DIRECTIONS], hp[RC_HIST_DIRECTIONS];
+        rc::Mat none2;
+        for (int t = 0, fc = 0; t < 4; t++) {
+            rc::Mat m(YDIM, XDIM, 1, 1, (void*)src[t % 3]->data());
+            if (!pipe.pushFrame(m, none2, 0.5, 2, 3, 2, 15, 1.2, 0)) continue;
+            fc++;
+            pipe.streamline_field(2, 1);
+            pipe.create_histogram(hh, hhs, hh2, hhs2, hu, hu2, hp);
+            pipe.create_flow_and_accumulationbuffer(mwant, fc);
+        }
+        for (int graph = 0; graph < 2; graph++) {
+            REQUIRE(rcflow_analysis_reset(pipe.context(), 0, XDIM, YDIM) == 0);
+            REQUIRE(rcflow_stream_reset(pipe.context(), 0) == 0);
+            for (int t = 0; t < 4; t++) {
+                rc::Mat buf = pipe.frameBuffer();
+                for (int y = 0; y < YDIM; y++) memcpy((uint8_t*)buf.data + (size_t)y * buf.step, src[t % 3]->data() + (size_t)y * XDIM, XDIM);
+                REQUIRE(pipe.loopStep(0.5, 2, 3, 2, 15, 1.2, 0, 2.f, 1, nullptr, 0, 100.f, 0.5f, 0.2f, graph == 1) == (t > 0));
+            }
+            REQUIRE(rcflow_sync(pipe.context(), 0) == 0);
+            REQUIRE(hipMemcpy(got.data(), pipe.outmaskDevice(), got.size(), hipMemcpyDeviceToHost) == hipSuccess);
+            REQUIRE(memcmp(got.data(), want.data(), got.size()) == 0);
+        }
     }
 
     // the asynchronous host loop: frames from host memory through the page-locked double buffer, the flow field
