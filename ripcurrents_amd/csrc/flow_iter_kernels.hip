@@ -1348,6 +1348,15 @@ int rc_flow_iter2_r0_reads(const RcIterArgs& a, int pairs) {
     return cp.ngroups ? cp.ngroups : pairs;
 }
 
+// The chain groups a launch would use (host logic only; the CPU tier checks its invariants through
+// rcflow_debug_chain_plan): returns the number of groups, 0 = independent pairs.
+int rc_flow_chain_groups(const RcIterArgs& a, int pairs, int* starts, int cap) {
+    RcChainPlan cp;
+    rc_chain_plan(a, pairs, (long long)((a.w + 27) / 28) * ((a.h + 27) / 28), cp);
+    for (int i = 0; i <= cp.ngroups && i < cap; i++) starts[i] = cp.start[i];
+    return cp.ngroups;
+}
+
 void rc_launch_flow_iter2(const RcIterArgs& a, int pairs, hipStream_t s) {
     const int g = a.win.gaussian ? 1 : 0;
     switch (a.in_mode * 2 + g) {

@@ -207,6 +207,7 @@ void rc_launch_polyexp_multi(const RcPolyArgs* a, int nlev, int frames, hipStrea
     /* two iterations in one launch (only where rc_flow_iter_can_fuse2 says so) */ \
     int rc_flow_iter_can_fuse2(const RcIterArgs& a);                          \
     int rc_flow_iter2_r0_reads(const RcIterArgs& a, int pairs);               \
+    int rc_flow_chain_groups(const RcIterArgs& a, int pairs, int* starts, int cap); \
     void rc_launch_flow_iter2(const RcIterArgs& a, int pairs, hipStream_t s);
 namespace rc_flow_fast { RC_FLOW_DECLS }
 namespace rc_flow_exact { RC_FLOW_DECLS }

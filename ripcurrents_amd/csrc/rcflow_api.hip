@@ -266,6 +266,17 @@ extern "C" int rcflow_debug_read_stamps(rc_ctx* ctx, long long* out, int n) {
     return RC_OK;
 }
 
+// Diagnostic (not part of include/rcflow.h; tests/test_cabi_and_host.py): the pair groups the fused winsize-3 kernel would
+// walk for a launch of `pairs` consecutive pairs of a w x h scale with option chain = `chain` -- pure host logic, no GPU.
+extern "C" int rcflow_debug_chain_plan(int w, int h, int pairs, int chain, int force, int* starts, int cap) {
+    if (w <= 0 || h <= 0 || pairs < 1 || !starts || cap < 2) return RC_EINVAL;
+    RcIterArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w = w; a.h = h; a.chain = chain; a.addr32 = 1; a.slot0 = 0; a.slot1 = 1; a.zstep = 1; a.nslots = pairs + 1;
+    a.ablate = force ? RC_ABL_FORCE_CHAIN : 0;
+    return rc_flow_fast::rc_flow_chain_groups(a, pairs, starts, cap);
+}
+
 // Diagnostic (not part of include/rcflow.h; scripts/r3/level_errors.py): the flow field a scale's last launch wrote
 // for pair 0 of the slot's last call -- valid for scales >= 1 after a call whose iterations fit one or two launches
 // per scale (buffer A then B alternate); which = 0 / 1 picks the buffer.
