@@ -1301,6 +1301,9 @@ extern "C" int rcflow_frame_loop_step(rc_ctx* ctx, int stream, const rc_farnebac
     RC_HIP(hipSetDevice(ctx->device));
     const int w = s->pin_w, h = s->pin_h, pin = s->pin_acq;
     int rc;
+    // the histogram stage's int32 guard, checked before anything is consumed or launched: a refused call leaves the
+    // acquired frame, the stream and the analysis state as they were (reset the segment, call again)
+    if (s->primed && s->an.w == w && s->an.h == h && (rc = rc_hist_book(*s, w, h, false))) return rc;
     if (!loop->use_graph) {
         // The default: the two-stream frame push (upload and expansion of this frame beside the previous frame's flow
         // and analysis kernels, which the slot's stream may still be executing) followed by the analysis launches --

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from ripcurrents_amd import synth
+from ripcurrents_amd import RcflowError, synth
 from ripcurrents_amd.api import HistState, Streakline
 
 pytestmark = pytest.mark.gpu
@@ -832,6 +832,44 @@ def test_frame_loop_step_matches_the_separate_calls(ctx, orc, use_graph):
             assert np.array_equal(x[j], y[j]), "snapshot %d: %s" % (i, name)
     assert a[-1][5].max() > 0            # the accumulator did start (framecount > 30)
     ctx.stream_reset()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_frame_loop_step_refuses_to_wrap_the_histogram(ctx, use_graph):
+    """The reference's `int` histogram counters (ripcurrents.cpp:147-150) wrap after 2^31 pixels -- 1035 frames of 1080p.
+    rcflow_frame_loop_step refuses the frame that would (RC_ESTATE) BEFORE consuming or launching anything: the acquired
+    frame buffer is still the caller's, the stream is intact, and after rcflow_histogram_reset_dev the same call goes
+    through and continues the flow from the frame before."""
+    w, h = 1920, 1080
+    limit = (2 ** 31 - 1) // (w * h)                 # 1035 flow fields fit
+    clip = synth.surf_clip(w, h, 3, seed=9)
+    ctx.stream_reset()
+    ctx.analysis_reset(w, h)
+    mask = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+    p = dict(pyr_scale=0.5, levels=2, winsize=3, poly_n=15, poly_sigma=1.2, flags=0)
+    order = [0, 1, 2, 1]
+    n = 0
+    for t in range(limit + 1):                       # the priming frame + `limit` flows
+        ctx.frame_buffer(w, h)[:] = clip[order[t % 4]]
+        f = ctx.frame_loop_step(w, h, outmask=mask, use_graph=use_graph, **p)
+        n += f is not None
+    assert n == limit
+    ctx.sync()
+    st = ctx.histogram_read()
+    assert 0 < st.histsum <= limit * w * h
+    ctx.frame_buffer(w, h)[:] = clip[order[(limit + 1) % 4]]
+    with pytest.raises(RcflowError) as e:
+        ctx.frame_loop_step(w, h, outmask=mask, use_graph=use_graph, **p)
+    assert e.value.code == -6                         # RC_ESTATE, nothing consumed
+    assert ctx.histogram_read().histsum == st.histsum
+    ctx.histogram_reset()
+    f = ctx.frame_loop_step(w, h, outmask=mask, use_graph=use_graph, **p)      # the same acquired frame goes through now
+    ctx.sync()
+    ref = ctx.calcOpticalFlowFarneback(clip[order[limit % 4]], clip[order[(limit + 1) % 4]], None, iterations=2, **p)
+    assert f is not None and np.array_equal(f.cpu().numpy(), ref)
+    assert 0 < ctx.histogram_read().histsum <= w * h
+    ctx.stream_reset()
+    ctx.analysis_reset(64, 48)
 
 
 def test_host_frame_loop_argument_and_state_errors(ctx):
