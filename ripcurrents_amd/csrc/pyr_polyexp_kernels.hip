@@ -485,13 +485,18 @@ __device__ __forceinline__ void rc_pyr2_rows(const RcPolyArgs& a, const unsigned
     float k[9];
 #pragma unroll
     for (int j = 0; j < 9; j++) k[j] = P.kern[j];
-    for (int item = tid; item < 38 * 32; item += RC_POLY_BLOCK) {
-        const int r = item >> 5, c = item & 31;
-        // source row ty0 - 3 + r; sampled column 4 (ox) + 1 + (c & 1) of output ox = c >> 1, taps -4 .. +4
-        const unsigned char* u0 = ub + (ty0 - 3 + r - row0) * pitch + (tx0 + 4 * (c >> 1) + 1 + (c & 1) - 4 - col0);
-        float b[9];
-        rc_lds_bytes_f32<9>(u0, b);
-        rp2[item] = rc_rowpass<4>(b, k);
+    // an item = the two sampled columns 4 ox + 1, 4 ox + 2 of output ox in one source row: their 9-tap windows share
+    // eight of ten bytes, so the bytes are fetched and converted once for both filters (608 items per tile)
+    for (int item = tid; item < 38 * 16; item += RC_POLY_BLOCK) {
+        const int r = item >> 4, ox = item & 15;
+        // source row ty0 - 3 + r; taps -4 .. +4 around columns tx0 + 4 ox + 1 and + 2
+        const unsigned char* u0 = ub + (ty0 - 3 + r - row0) * pitch + (tx0 + 4 * ox + 1 - 4 - col0);
+        float b[10];
+        rc_lds_bytes_f32<10>(u0, b);
+        float2 o;
+        o.x = rc_rowpass<4>(b, k);
+        o.y = rc_rowpass<4>(b + 1, k);
+        *(float2*)(rp2 + r * 32 + 2 * ox) = o;
     }
 }
 
