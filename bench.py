@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="library option for same-box A/B runs (rcflow_set_option), e.g. --opt chain=1")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--event-every", type=int, default=10,
+    ap.add_argument("--event-every", type=int, default=20,
                     help="bracket every kernel of every Nth timed step with HIP events (1 = every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roof", action="store_true", help="skip the measured memory roof (read/fill/copy microbench)")
