@@ -439,6 +439,9 @@ void rc_launch_pyr(const RcPyrArgs& a, int frames, size_t lds, hipStream_t s) {
 #ifndef RC_POLY_ABL
 #define RC_POLY_ABL 0     // timing-only ablations (never in the product): 1 = no R stores, 2 = the stores alone, 3 = staging + blur + pyramid alone, 4 = no staging loads
 #endif
+#ifndef RC_POLY_EPI32
+#define RC_POLY_EPI32 1   // epilogue of the fast expansion: split-constant fp32 (1) or double (0); measured -2 % of the kernel, parity statistics unchanged
+#endif
 #ifndef RC_POLY_B128
 #define RC_POLY_B128 1    // horizontal pass: window reads as forced ds_read_b128 (0 = the compiler's choice)
 #endif
@@ -929,6 +932,14 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
         float* RB = a.RB + (size_t)slot * a.R_slot_stride;
         const double dck = (double)dc * a.pk.kdc;
         const float ig11f = (float)a.pk.ig11, ig55f = (float)a.pk.ig55;
+#if RC_POLY_EPI32
+        // yy / xx = b1 ig03 + b5 ig33 + dc kdc with the three double constants split into float pairs (hi + lo): the hi
+        // chain carries the value, the lo chain the constants' rounding -- eight fp32 operations per pixel instead of
+        // twelve at fp64 rate; what is left is the rounding of the hi chain's two partial sums (<= 1 ulp each)
+        const float ig03h = (float)a.pk.ig03, ig03l = (float)(a.pk.ig03 - (double)ig03h);
+        const float ig33h = (float)a.pk.ig33, ig33l = (float)(a.pk.ig33 - (double)ig33h);
+        const float dckh = (float)dck, dckl = (float)(dck - (double)dckh);
+#endif
         RC_PSTAMP(5);
 #pragma unroll
         for (int o = 0; o < NR; o++) {
@@ -941,8 +952,14 @@ __device__ __forceinline__ void rc_polyexp_body(const RcPolyArgs& a, int bx, int
                 float4 ra;
                 ra.x = b3[o] * ig11f;
                 ra.y = b2[o] * ig11f;
+#if RC_POLY_EPI32
+                const float th = RC_FMA(b1[o], ig03h, dckh), tl = RC_FMA(b1[o], ig03l, dckl);
+                ra.z = RC_FMA(b5[o], ig33h, th) + RC_FMA(b5[o], ig33l, tl);
+                ra.w = RC_FMA(b4[o], ig33h, th) + RC_FMA(b4[o], ig33l, tl);
+#else
                 ra.z = (float)((double)b1[o] * a.pk.ig03 + (double)b5[o] * a.pk.ig33 + dck);
                 ra.w = (float)((double)b1[o] * a.pk.ig03 + (double)b4[o] * a.pk.ig33 + dck);
+#endif
                 size_t p = (size_t)gy * w + gx;
                 // streaming stores: R is written once here and read by the flow kernels much later (the
                 // batch's R does not fit the caches), and this kernel is bound by its writes (-1.4 % per pair)
