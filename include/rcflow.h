@@ -94,7 +94,8 @@ int rcflow_use_own_stream(rc_ctx* ctx, int stream);
  * launch (default 1; results are bit-identical either way);
  * "chain" = consecutive frame pairs a block of the fused winsize-3 flow kernel walks on its tile, taking pair
  * z + 1's previous-frame coefficients out of pair z's next-frame window in LDS (the reference's u_f1.copyTo(u_f2),
- * ripcurrents.cpp:194-221, at tile level; default 8, 1 = off; shortened automatically for small launches; same bits).
+ * ripcurrents.cpp:194-221, at tile level; default 8, 1 = off; halved for small launches until "chain_min_blocks" blocks
+ * (default 4096) remain; same bits).
  * Measurement switches, all speed-only except where noted: "xcd_remap" (1) XCD-aware tile order;
  * "poly_tile_h" (32 | 48) rows per expansion block -- changes the per-tile DC and with it the last
  * bits of R; "poly_mfma" (0) vertical pass of the expansion on the matrix cores -- different

@@ -1303,14 +1303,14 @@ static void launch_rrc_t(RcIterArgs a, const RcChainPlan& cp, int pairs, hipStre
 // Chain groups of a launch of `pairs` consecutive pairs: runs of `chain` pairs, then halving runs over the last
 // `chain` pairs (8, 8, 8, 4, 2, 1, 1 for 32 pairs and chain 8) so that the blocks still running when the grid
 // drains are short ones -- a long-lived block in the last wave of a launch idles the rest of the GPU.  The chain
-// is shortened until the launch still has ~8 blocks per block slot of the GPU (1024 = 256 CUs x 4).
+// is halved until the launch still has ~4 blocks per block slot of the GPU (1024 = 256 CUs x 4; measured: 4096).
 static void rc_chain_plan(const RcIterArgs& a, int pairs, long long tiles, RcChainPlan& cp) {
     cp.ngroups = 0;
     const bool chainable = a.chain > 1 && pairs > 1 && (a.slot0 + a.zstep) % a.nslots == a.slot1 % a.nslots;
     if (!chainable) return;
     int chain = a.chain;
     if (!(a.ablate & RC_ABL_FORCE_CHAIN))
-        while (chain > 1 && tiles * pairs / chain < 8192) chain >>= 1;
+        while (chain > 1 && tiles * pairs / chain < (a.chain_min_blocks > 0 ? a.chain_min_blocks : 4096)) chain >>= 1;
     if (chain <= 1) return;
     int n = 0, z = 0;
     cp.start[0] = 0;

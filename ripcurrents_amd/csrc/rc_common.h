@@ -138,6 +138,7 @@ struct RcIterArgs {
     int xcd_remap;            // XCD-aware tile order (speed only)
     int ablate;               // timing-only ablation bits (0 in production)
     int addr32;               // every offset inside one frame's R planes and one pair's flow field fits 32 bits (set by the level driver)
+    int chain_min_blocks;     // option "chain_min_blocks": a launch keeps at least this many blocks when its chains are shortened (0 = 4096)
     int chain;                // option "chain": consecutive pairs a block of the fused winsize-3 kernel walks on its tile (<= 1: none)
     RcWindow win;
 };

@@ -105,6 +105,7 @@ struct rc_ctx {
     int exact_taps = 0;
     int exact = -1;            // option "exact": upstream's CPU operation order (exact_kernels.hip); -1 = where the fast path cannot hold the tolerance
     int fuse_iters = 1;
+    int chain_min_blocks = 0;  // option "chain_min_blocks" (0 = the kernel's default, 4096)
     int chain = 8;             // option "chain": pairs per tile chain of the fused winsize-3 flow kernel (1 = off)
     int xcd_remap = 1;
     int poly_tile_h = 32;

@@ -304,6 +304,9 @@ extern "C" int rcflow_set_option(rc_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "chain")) {
         if (value < 1 || value > 64) return RC_EINVAL;
         ctx->chain = value;
+    } else if (!strcmp(name, "chain_min_blocks")) {
+        if (value < 0) return RC_EINVAL;
+        ctx->chain_min_blocks = value;
     } else if (!strcmp(name, "xcd_remap")) {
         ctx->xcd_remap = value ? 1 : 0;
     } else if (!strcmp(name, "hist_blocks")) {
@@ -795,6 +798,7 @@ static int compute_flows(rc_ctx* ctx, RcSlot& s, int pairs, int slot0, float* d_
         a.xcd_remap = ctx->xcd_remap;
         a.ablate = ctx->ablate;
         a.chain = ctx->chain;
+        a.chain_min_blocks = ctx->chain_min_blocks;
         const float2* cur_in = nullptr;
         int passes = iters > 0 ? iters : 1;
         int nout = 0;   // intermediate buffers written so far at this scale (ping-pong index)

@@ -153,7 +153,7 @@ def test_bench_self_launch_command():
 def test_tile_chain_plan_invariants():
     """Host logic of the fused winsize-3 flow kernel's tile chains (option `chain`): the pair groups of a launch cover
     every pair exactly once in order, no group is longer than the option, the groups over the last `chain` pairs halve
-    (the launch drains on short blocks), a launch too small to keep ~8 blocks per block slot of the GPU shortens its
+    (the launch drains on short blocks), a launch too small to keep ~4 blocks per block slot of the GPU shortens its
     chains or gets none, and chain <= 1 means independent pairs.  Pure host code: runs without a GPU."""
     import ripcurrents_amd
     lib = ripcurrents_amd.load()
@@ -170,8 +170,8 @@ def test_tile_chain_plan_invariants():
     assert plan(1920, 1080, 32, 8) == [0, 8, 16, 24, 28, 30, 31, 32]          # 8, 8, 8, then 4, 2, 1, 1
     assert plan(1920, 1080, 32, 1) == [] and plan(1920, 1080, 1, 8) == []     # independent pairs
     assert plan(480, 270, 32, 8) == []                                        # scale 2 of 1080p: too few blocks for chains
-    p1 = plan(960, 540, 32, 8)                                                # scale 1: chains of 2
-    assert p1 and max(b - a for a, b in zip(p1, p1[1:])) == 2
+    p1 = plan(960, 540, 32, 8)                                                # scale 1: chains of 4
+    assert p1 and max(b - a for a, b in zip(p1, p1[1:])) == 4
     for (w, h, pairs, chain, force) in [(1920, 1080, 32, 8, 0), (3840, 2160, 8, 8, 0), (640, 480, 9, 4, 1), (257, 130, 11, 64, 1),
                                         (1920, 1080, 64, 3, 0), (1920, 1080, 5, 2, 1), (333, 251, 63, 8, 1)]:
         st = plan(w, h, pairs, chain, force)
