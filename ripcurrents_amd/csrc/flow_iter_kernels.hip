@@ -875,11 +875,13 @@ template <int GAUSS_, int NIT, int MW, int NG>
 __device__ __forceinline__ void rc_rr_flows(const float (&m)[NIT][5], const float* XR, int grp, int x,
                                             const RcWindow& win, float2 (&f)[NIT]) {
     const int gu = max(grp - 1, 0), gd = min(grp + 1, NG - 1);
+    // XR[group][first / last][channel][MW]: group stride 10 MW by a 24-bit multiply (a 32-bit one runs at quarter rate)
+    const int bu = (int)__umul24((unsigned)gu, 10u * MW) + x, bd = (int)__umul24((unsigned)gd, 10u * MW) + x;
     float up[5], dn[5];
 #pragma unroll
     for (int c = 0; c < 5; c++) {
-        up[c] = XR[((gu * 2 + 1) * 5 + c) * MW + x];
-        dn[c] = XR[((gd * 2 + 0) * 5 + c) * MW + x];
+        up[c] = XR[bu + (5 + c) * MW];
+        dn[c] = XR[bd + c * MW];
     }
     float V[NIT][5];
 #pragma unroll
@@ -907,10 +909,11 @@ __device__ __forceinline__ void rc_rr_flows(const float (&m)[NIT][5], const floa
 
 template <int NIT, int MW>
 __device__ __forceinline__ void rc_rr_exchange(const float (&m)[NIT][5], float* XR, int grp, int x) {
+    const int b = (int)__umul24((unsigned)grp, 10u * MW) + x;
 #pragma unroll
     for (int c = 0; c < 5; c++) {
-        XR[((grp * 2 + 0) * 5 + c) * MW + x] = m[0][c];
-        XR[((grp * 2 + 1) * 5 + c) * MW + x] = m[NIT - 1][c];
+        XR[b + c * MW] = m[0][c];
+        XR[b + (5 + c) * MW] = m[NIT - 1][c];
     }
 }
 
@@ -952,10 +955,12 @@ __device__ __forceinline__ void rc_rr_flow_in(const RcIterArgs& a, const float2*
         const bool cols_plain = INTERIOR || (tx0 - 2 >= 1 && tx0 - 2 + MW <= w && ((tx0 - 2 + MW - 2) >> 1) + 1 <= a.fin_w - 1);
         if (INTERIOR) {
             // (an interior block's coarse rows rb .. rb + NR - 1 and columns sx, sx + 1 all exist)
+            unsigned co = (unsigned)(__mul24(rb, a.fin_w) + sx);
 #pragma unroll
             for (int j = 0; j < NR; j++) {
-                const rc_f4a8 v = *(const rc_f4a8*)(fin + (unsigned)((rb + j) * a.fin_w + sx));
+                const rc_f4a8 v = *(const rc_f4a8*)(fin + co);
                 t0[j] = make_float2(v.x, v.y); t1[j] = make_float2(v.z, v.w);
+                co += (unsigned)a.fin_w;
             }
         } else if (cols_plain) {
 #pragma unroll
@@ -1039,6 +1044,13 @@ __device__ __forceinline__ void rc_rr_flow_in(const RcIterArgs& a, const float2*
 __device__ __forceinline__ void rc_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void rc_all_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+constexpr bool rc_recip_exact(int nt, int wp) {
+    const unsigned r = (65536u + wp - 1) / wp;
+    for (int t = 0; t < nt; t++)
+        if ((int)((t * r) >> 16) != t / wp) return false;
+    return true;
+}
+
 // LDS-DMA with a wave-uniform base in SGPRs, a 32-bit byte offset per lane and the wave's LDS destination as a
 // plain byte address in M0 (no 64-bit address arithmetic, no generic-pointer casts).
 __device__ __forceinline__ void rc_glds16_s(const void* base, unsigned voff, uint32_t lds_wave_addr) {
@@ -1056,8 +1068,10 @@ __device__ __forceinline__ void rc_rrc_issue_window(const float4* __restrict__ R
                                                     uint32_t lds_a, uint32_t lds_b, int tid, int ox, int oy, int w, int h) {
     constexpr int QY = NT / WP, QX = NT % WP;
     const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
-    int wy = tid / WP, wx = tid - wy * WP;
-    int off = (oy + wy) * w + ox + wx;
+    // tid / WP by a 24-bit multiply and shift (checked at compile time for every tid < NT), no 32-bit integer multiply
+    static_assert(rc_recip_exact(NT, WP), "tid / WP by multiply and shift must be exact for every thread");
+    int wy = (int)(__umul24((unsigned)tid, (65536u + WP - 1) / WP) >> 16), wx = tid - (int)__umul24((unsigned)wy, (unsigned)WP);
+    int off = __mul24(oy + wy, w) + ox + wx;
 #pragma unroll
     for (int q = 0; q < NWL; q++) {
         bool ok = (q + 1) * NT <= WN || tid + q * NT < WN;
@@ -1099,16 +1113,22 @@ __device__ __forceinline__ void rc_rr_matrices(float (&m)[NIT][5], const float4 
         for (int q = 0; q < NIT; q++) {
             RcGather g;
             const float fx = gxo + dx[q], fy = gys[q] + dy[q];
-            const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
-            g.fx = fx - x1;
-            g.fy = fy - y1;
+            // (float)(int)floorf(v) == floorf(v) for every coordinate an image can have: the fraction is taken against
+            // the floor itself (one conversion less per coordinate), the index is a 24-bit multiply-add (full rate; a
+            // 32-bit integer multiply runs at a quarter of it)
+            const float flx = floorf(fx), fly = floorf(fy);
+            const int x1 = (int)flx, y1 = (int)fly;
+            g.fx = fx - flx;
+            g.fy = fy - fly;
             g.inside = true;
             const int wx = x1 - ox, wy = y1 - oy;
             const bool in_win = (unsigned)wx < (unsigned)(WW - 1) && (unsigned)wy < (unsigned)(WH - 1);
             far |= in_win ? 0u : 1u << q;
-            const int i = in_win ? wy * WP + wx : 0;
-            g.q00 = LA[i]; g.q01 = LA[i + 1]; g.q10 = LA[i + WP]; g.q11 = LA[i + WP + 1];
-            g.e00 = LB[i]; g.e01 = LB[i + 1]; g.e10 = LB[i + WP]; g.e11 = LB[i + WP + 1];
+            const unsigned i = in_win ? __umul24((unsigned)wy, (unsigned)WP) + (unsigned)wx : 0u;
+            const float4* pa = (const float4*)((const char*)LA + (i << 4));      // (two shifts: the compiler otherwise derives the
+            const float* pb = (const float*)((const char*)LB + (i << 2));        //  float plane's address by a 64-bit multiply-add)
+            g.q00 = pa[0]; g.q01 = pa[1]; g.q10 = pa[WP]; g.q11 = pa[WP + 1];
+            g.e00 = pb[0]; g.e01 = pb[1]; g.e10 = pb[WP]; g.e11 = pb[WP + 1];
             RcM5 v = rc_matrices_reg(A0[q], B0[q], g, dx[q], dy[q], gxo, gys[q], w, h, false);
             m[q][0] = v.m0; m[q][1] = v.m1; m[q][2] = v.m2; m[q][3] = v.m3; m[q][4] = v.m4;
         }
@@ -1221,7 +1241,7 @@ __device__ __forceinline__ void rc_rrc_body(const RcIterArgs& a, const int zb, c
         if (more) {
 #pragma unroll
             for (int q = 0; q < NIT; q++) {
-                const int i = (gys[q] - oy) * WP + (gxo - ox);
+                const int i = (int)__umul24((unsigned)(gys[q] - oy), (unsigned)WP) + (gxo - ox);
                 A0[q] = LA[i];
                 B0[q] = LB[i];
             }
@@ -1262,11 +1282,13 @@ __device__ __forceinline__ void rc_rrc_body(const RcIterArgs& a, const int zb, c
             float2 f2[NIT];
             rc_rr_flows<GAUSS_, NIT, MW, NG>(m, XR, grp, x, a.win, f2);
             if (x >= 2 && x < MW - 2 && (INTERIOR || px < w)) {
+                // (a.addr32: 32-bit offsets; one multiply for the thread's first row, the others follow by addition)
+                unsigned so = (unsigned)(ty0 - 2 + ly0) * (unsigned)a.fout_step + (unsigned)px * 8u;
 #pragma unroll
                 for (int q = 0; q < NIT; q++) {
                     const int ly = ly0 + q, py = ty0 - 2 + ly;
-                    if (ly >= 2 && ly < MH - 2 && (INTERIOR || py < h))
-                        *(float2*)(fout + ((unsigned)py * (unsigned)a.fout_step + (unsigned)px * 8u)) = f2[q];   // (a.addr32)
+                    if (ly >= 2 && ly < MH - 2 && (INTERIOR || py < h)) *(float2*)(fout + so) = f2[q];
+                    so += (unsigned)a.fout_step;
                 }
             }
         }
