@@ -91,9 +91,23 @@ __device__ __forceinline__ void rc_gather_issue(RcGather& g, const float4* __res
     g.e00 = RB1[p]; g.e01 = RB1[p + p1]; g.e10 = RB1[p + pw]; g.e11 = RB1[p + pw + p1];
 }
 
+#ifndef RC_HALF_WEIGHTS
+#define RC_HALF_WEIGHTS 1     // fast build: the averages with R0 folded into the interpolation (0 = the separate sums of round 2)
+#endif
+#if defined(RC_EXACT_BUILD) || !RC_HALF_WEIGHTS
+#define RC_M_PLAIN 1
+#endif
+// R0 as rc_matrices_reg takes it: halved in the fast build (exact: a power of two), untouched in the exact build
+__device__ __forceinline__ void rc_r0_prep(float4& A0, float& B0) {
+#ifndef RC_M_PLAIN
+    A0.x *= 0.5f; A0.y *= 0.5f; A0.z *= 0.5f; A0.w *= 0.5f; B0 *= 0.5f;
+#endif
+}
+
 __device__ __forceinline__ RcM5 rc_matrices_reg(const float4 A0, const float B0, const RcGather& g, float dx,
                                                 float dy, int X, int Y, int w, int h, bool BORDER = true) {
     float fx = g.fx, fy = g.fy;
+#ifdef RC_M_PLAIN
     float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy);
     float a10 = (1.f - fx) * fy, a11 = fx * fy;
 #ifdef RC_EXACT_BUILD
@@ -115,6 +129,26 @@ __device__ __forceinline__ RcM5 rc_matrices_reg(const float4 A0, const float B0,
     }
     r2 = (A0.x - r2) * 0.5f;
     r3 = (A0.y - r3) * 0.5f;
+#else
+    // The averages with R0 ((R0 -/+ bilinear) / 2, xy: / 4) folded into the interpolation: HALF weights (0.5 a_ij,
+    // exact: a power of two) and the chain started at R0 / 2 -- four fused multiply-adds per coefficient instead of a
+    // product, three of them, a sum and a scaling.  A0 / B0 arrive HALVED in this build (rc_r0_prep, once per pair: both
+    // iterations of a launch use the same R0).
+    const float hx1 = 0.5f * fx, hx0 = RC_FMA(fx, -0.5f, 0.5f), fy0 = 1.f - fy;
+    const float h00 = hx0 * fy0, h01 = hx1 * fy0, h10 = hx0 * fy, h11 = hx1 * fy;
+#define RC_BILIN_FROM(s0, sg, c, e) RC_FMA(sg h11, e##11 c, RC_FMA(sg h10, e##10 c, RC_FMA(sg h01, e##01 c, RC_FMA(sg h00, e##00 c, s0))))
+    float r2 = RC_BILIN_FROM(A0.x, -, .x, g.q), r3 = RC_BILIN_FROM(A0.y, -, .y, g.q);
+    float r4 = RC_BILIN_FROM(A0.z, +, .z, g.q), r5 = RC_BILIN_FROM(A0.w, +, .w, g.q);
+    float r6 = 0.5f * RC_BILIN_FROM(B0, +, , g.e);
+#undef RC_BILIN_FROM
+    if (!g.inside) {
+        r2 = A0.x;
+        r3 = A0.y;
+        r4 = 2.f * A0.z;
+        r5 = 2.f * A0.w;
+        r6 = B0;
+    }
+#endif
 #ifdef RC_EXACT_BUILD
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
@@ -157,6 +191,7 @@ __device__ __forceinline__ RcM5 rc_matrices(const float4* __restrict__ RA0, cons
     float B0 = RB0[p0];
     RcGather g;
     rc_gather_issue(g, RA1, RB1, gx, gy, dx, dy, w, h);
+    rc_r0_prep(A0, B0);
     return rc_matrices_reg(A0, B0, g, dx, dy, gx, gy, w, h);
 }
 
@@ -725,6 +760,7 @@ __global__ __launch_bounds__(RC_W3_THREADS) void k_flow_iter_w3(RcIterArgs a) {
         size_t p0 = (size_t)gy[q] * w + gx[q];
         A0[q] = RA0[p0];
         B0[q] = RB0[p0];
+        rc_r0_prep(A0[q], B0[q]);
         rc_gather_issue(gt[q], RA1, RB1, gx[q], gy[q], dx[q], dy[q], w, h);
     }
     // ---- FarnebackUpdateMatrices
@@ -1186,6 +1222,7 @@ __device__ __forceinline__ void rc_rrc_body(const RcIterArgs& a, const int zb, c
             const unsigned p0 = (unsigned)(gys[q] * w + gxo);
             A0[q] = (a.RA + s0)[p0];
             B0[q] = (a.RB + s0)[p0];
+            rc_r0_prep(A0[q], B0[q]);
         }
         rc_rr_flow_in<IN_MODE, NIT, MW, MH, INTERIOR>(a, a.fin + (size_t)zb * a.fin_pair_stride, tx0, ty0, gxo, gys, dx, dy);
     }
@@ -1244,6 +1281,7 @@ __device__ __forceinline__ void rc_rrc_body(const RcIterArgs& a, const int zb, c
                 const int i = (int)__umul24((unsigned)(gys[q] - oy), (unsigned)WP) + (gxo - ox);
                 A0[q] = LA[i];
                 B0[q] = LB[i];
+                rc_r0_prep(A0[q], B0[q]);
             }
         }
         rc_lds_barrier();     // the exchange rows and the R1 window have been read by everyone
