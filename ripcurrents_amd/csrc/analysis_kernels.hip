@@ -182,36 +182,40 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist(const float* flow0, siz
 //    goes through the wave-level step: the first lane's key is broadcast, the counts of all lanes holding it are
 //    summed with DPP / permute steps and added by one LDS atomic; lanes holding another key add their own pair.
 //    One scalar round per 8 pixels instead of one per pixel.
+#ifndef RC_HIST_ABL
+#define RC_HIST_ABL 0     // diagnostic builds only (scripts/r3/variant_ana.sh)
+#endif
 __device__ __forceinline__ int rc_hist_key_fast(float2 f, bool& exact_needed) {
     const float s = f.x * f.x + f.y * f.y;
-    const float m = s > 0.f ? s * __builtin_amdgcn_rsqf(s) : s;      // s = 0, NaN: m = s
+    const float m = __builtin_amdgcn_sqrtf(s);                       // v_sqrt_f32 (1 ulp); 0 -> 0, NaN -> NaN, inf -> inf
     const float t = m * (float)RC_HIST_RESOLUTION;
-    const float rt = rintf(t);
-    // direction: OpenCV's polynomial on lo / hi with the quotient as a product
+    // direction: OpenCV's polynomial on lo / hi with the quotient as a product (fused multiply-adds: this value only has
+    // to land within a few ulps of the reference's, the guard below covers the rest)
     const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
     const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
     const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
     const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
     const float ax = fabsf(f.x), ay = fabsf(f.y);
     const bool xmajor = ax >= ay;
-    const float lo = xmajor ? ay : ax, hi = xmajor ? ax : ay;
+    const float lo = __builtin_fminf(ax, ay), hi = __builtin_fmaxf(ax, ay);
     const float c = lo * __builtin_amdgcn_rcpf(hi + (float)DBL_EPSILON);
     const float c2 = c * c;
-    float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    float a = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(p7, c2, p5), c2, p3), c2, p1) * c;
     if (!xmajor) a = 90.f - a;
     if (f.x < 0) a = 180.f - a;
     if (f.y < 0) a = 360.f - a;
     const float u = a * ((float)RC_HIST_DIRECTIONS / 360.f);
-    const float ru = rintf(u);
-    // (comparisons written so that a NaN fails them)
-    const bool mag_ok = fabsf(t - rt) > 1e-4f && t < 1e6f;
-    const bool dir_ok = fabsf(u - ru) > 1e-4f;
-    const int bin = (int)t;                                          // t < 1e6 where it is used
-    const bool counted = bin < RC_HIST_BINS;                         // t >= 0 always
+    // "within 1e-4 of an integer" on the fractional parts: |fract - 1/2| > 1/2 - 1e-4 (a NaN or an infinity fails the
+    // comparisons below and takes the exact path too)
+    const float gt = fabsf(__builtin_amdgcn_fractf(t) - 0.5f), gu = fabsf(__builtin_amdgcn_fractf(u) - 0.5f);
+    const bool mag_ok = gt < 0.4999f;
+    const bool dir_ok = gu < 0.4999f;
+    const int bin = __float2int_rz(t);                               // saturating conversion; t >= 0 or NaN (-> 0, flagged)
+    const bool counted = bin < RC_HIST_BINS;
     exact_needed = !mag_ok || (counted && !dir_ok);
-    int d = (int)u;
-    if (d >= RC_HIST_DIRECTIONS || d < 0) d = 0;
-    return counted ? d * RC_HIST_BINS + bin : -1;
+    // (int)u < 36 wherever dir_ok holds: u = 36 needs a >= 359.99999, whose fractional part fails the guard
+    const int d = __float2int_rz(u);
+    return counted ? (int)__umul24((unsigned)d, (unsigned)RC_HIST_BINS) + bin : -1;
 }
 
 __device__ __forceinline__ int rc_wave_sum(int v) {
@@ -220,6 +224,8 @@ __device__ __forceinline__ int rc_wave_sum(int v) {
     return v;
 }
 
+// PLAIN (decided by the launcher, rc_hist_rows_plain): every item whole and every row 16-byte aligned.
+template <bool PLAIN>
 __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist_rows(const float* flow0, size_t frame_stride, size_t step,
                                                               int w, int h, int* parts) {
     __shared__ int lh[RC_HIST_DIRECTIONS * RC_HIST_BINS];
@@ -237,10 +243,30 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist_rows(const float* flow0
     const int lane = threadIdx.x & 63;
     float4 vn[NR];
     int nn[NR];
+    // PLAIN: one 32-bit offset per item and a scalar base per row -- four loads and a handful of address instructions
+    // where the general form spends ~120 on bounds, alignment and 64-bit row addresses.  A template parameter, not a
+    // run-time flag: with both forms in one loop the number of loads in flight at the keys depends on the path taken
+    // and the compiler waits for all of them (vmcnt(0)), i.e. for the prefetch it has just issued.
+    constexpr bool plain = PLAIN;
     auto load_item = [&](int it) {
         const int g = gg, x = xx * 2;
         gg += dg; xx += dx;
         if (xx >= w2) { xx -= w2; gg++; }
+        if constexpr (plain) {
+            // The four loads are issued by every lane in every round (a lane without an item reads the frame's first
+            // texels): were they under a branch, the number of loads in flight at the keys below would depend on the
+            // path and the compiler would have to wait for all of them -- the prefetch would overlap nothing.
+            const bool valid = it < rounds && g < hg;
+            const unsigned off = valid ? (unsigned)(g * NR) * (unsigned)step + (unsigned)x * 8u : 0u;
+            typedef float rc_f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                nn[r] = valid ? 2 : 0;
+                const rc_f4 t = __builtin_nontemporal_load((const rc_f4*)((const char*)flow + (size_t)r * step + off));
+                vn[r] = make_float4(t.x, t.y, t.z, t.w);
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             nn[r] = 0;
@@ -268,9 +294,32 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist_rows(const float* flow0
         int nv[NR];
 #pragma unroll
         for (int r = 0; r < NR; r++) { v[r] = vn[r]; nv[r] = nn[r]; }
-        if (it + 1 < rounds) load_item(it + 1);
+        if (plain || it + 1 < rounds) load_item(it + 1);     // (plain: past the last round the loads are the dummy ones)
         int k[2 * NR];
         bool redo = false;
+#if RC_HIST_ABL == 2     // timing-only build: the loads alone
+        {
+            float acc = 0.f;
+#pragma unroll
+            for (int r = 0; r < NR; r++) acc += v[r].x + v[r].y + v[r].z + v[r].w;
+            if (acc == 12345.678f) atomicAdd(&lh[0], 1);
+            continue;
+        }
+#endif
+        if constexpr (plain) {
+            // (a lane without an item skips the keys altogether: whole waves do in the last round)
+#pragma unroll
+            for (int i = 0; i < 2 * NR; i++) k[i] = -1;
+            if (nv[0]) {
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    bool e0, e1;
+                    k[2 * r] = rc_hist_key_fast(make_float2(v[r].x, v[r].y), e0);
+                    k[2 * r + 1] = rc_hist_key_fast(make_float2(v[r].z, v[r].w), e1);
+                    redo |= e0 || e1;
+                }
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             bool e0, e1;
@@ -280,6 +329,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist_rows(const float* flow0
             k[2 * r + 1] = nv[r] >= 2 ? k1 : -1;
             redo |= (nv[r] >= 1 && e0) || (nv[r] >= 2 && e1);
         }
+        }
         if (redo) {                              // a pixel near a bin / direction edge: the reference's own arithmetic
 #pragma unroll
             for (int r = 0; r < NR; r++) {
@@ -287,6 +337,15 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist_rows(const float* flow0
                 if (nv[r] >= 2) k[2 * r + 1] = rc_hist_key(make_float2(v[r].z, v[r].w));
             }
         }
+#if RC_HIST_ABL == 1     // timing-only build: loads and keys, no aggregation
+        {
+            int acc = 0;
+#pragma unroll
+            for (int i = 0; i < 2 * NR; i++) acc ^= k[i];
+            if (acc == 0x12345678) atomicAdd(&lh[0], 1);
+            continue;
+        }
+#endif
         // lane level: the first key and its multiplicity; other keys singly
         const int A = k[0];
         int cnt = 1;
@@ -857,9 +916,10 @@ extern "C" int rcflow_histogram_clip_dev(rc_ctx* ctx, int stream, const float* d
         RcProfScope ps(ctx, s->cur, RC_K_HIST, 0, 8. * w * h * count);
         long long per_frame = ((long long)(w + 1) / 2) * h;
         int nb = grid_for(per_frame);
-        // many light blocks (measured: 16384 total beat 2048 by 25 %): the partial tables keep
-        // the flush chains short, and one ballot round catches the dominant bin of a wave
-        int cap = (ctx->hist_blocks > 0 ? ctx->hist_blocks : 16384) / count;
+        // many light blocks: the partial tables keep the flush chains short, and one ballot round catches the dominant
+        // bin of a wave.  8192 blocks per launch = four items per thread at 32 frames of 1080p: one more round of prefetch
+        // than 16384 (134 -> 129 us), 4096: 131, 32768: 147 (profiles/r03_notes.md)
+        int cap = (ctx->hist_blocks > 0 ? ctx->hist_blocks : 8192) / count;
         if (cap < 8) cap = 8;
         if (nb > cap) nb = cap;
         if (ctx->ablate & RC_ABL_HIST_V1) {
@@ -869,8 +929,16 @@ extern "C" int rcflow_histogram_clip_dev(rc_ctx* ctx, int stream, const float* d
             // items are 2 x 4 pixel columns: a quarter of the items of the first form for the same block count
             int nb4 = grid_for(((long long)(w + 1) / 2) * ((h + 3) / 4));
             if (nb4 > cap) nb4 = cap;
-            hipLaunchKernelGGL(k_polar_hist_rows, dim3(nb4, count), dim3(RC_BLOCK), 0, s->cur, d_flows, flow_frame_stride,
-                               flow_step, w, h, (int*)s->an.hist_part.p);
+            // every item whole (even width, height a multiple of the item's four rows), every row of every frame 16-byte
+            // aligned, offsets inside a frame below 4 GB: the kernel's plain form
+            const bool plain = ((w & 1) | (h & 3)) == 0 && ((((size_t)d_flows) | flow_step | (count > 1 ? flow_frame_stride : 0)) & 15) == 0 &&
+                               (size_t)h * flow_step < ((size_t)1 << 32);
+            if (plain)
+                hipLaunchKernelGGL(k_polar_hist_rows<true>, dim3(nb4, count), dim3(RC_BLOCK), 0, s->cur, d_flows, flow_frame_stride,
+                                   flow_step, w, h, (int*)s->an.hist_part.p);
+            else
+                hipLaunchKernelGGL(k_polar_hist_rows<false>, dim3(nb4, count), dim3(RC_BLOCK), 0, s->cur, d_flows, flow_frame_stride,
+                                   flow_step, w, h, (int*)s->an.hist_part.p);
         }
         hipLaunchKernelGGL(k_hist_fold, dim3((RC_HIST_DIRECTIONS * RC_HIST_BINS + RC_BLOCK - 1) / RC_BLOCK),
                            dim3(RC_BLOCK), 0, s->cur, (int*)s->an.hist_part.p, (int*)s->an.hist.p);
