@@ -306,6 +306,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist_rows(const float* flow0
             continue;
         }
 #endif
+        unsigned em = 0;                         // bit i: key i has to be taken again with the reference's own arithmetic
         if constexpr (plain) {
             // (a lane without an item skips the keys altogether: whole waves do in the last round)
 #pragma unroll
@@ -316,25 +317,28 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist_rows(const float* flow0
                     bool e0, e1;
                     k[2 * r] = rc_hist_key_fast(make_float2(v[r].x, v[r].y), e0);
                     k[2 * r + 1] = rc_hist_key_fast(make_float2(v[r].z, v[r].w), e1);
-                    redo |= e0 || e1;
+                    em |= (e0 ? 1u : 0u) << (2 * r) | (e1 ? 1u : 0u) << (2 * r + 1);
                 }
             }
         } else {
 #pragma unroll
-        for (int r = 0; r < NR; r++) {
-            bool e0, e1;
-            const int k0 = rc_hist_key_fast(make_float2(v[r].x, v[r].y), e0);
-            const int k1 = rc_hist_key_fast(make_float2(v[r].z, v[r].w), e1);
-            k[2 * r] = nv[r] >= 1 ? k0 : -1;
-            k[2 * r + 1] = nv[r] >= 2 ? k1 : -1;
-            redo |= (nv[r] >= 1 && e0) || (nv[r] >= 2 && e1);
+            for (int r = 0; r < NR; r++) {
+                bool e0, e1;
+                const int k0 = rc_hist_key_fast(make_float2(v[r].x, v[r].y), e0);
+                const int k1 = rc_hist_key_fast(make_float2(v[r].z, v[r].w), e1);
+                k[2 * r] = nv[r] >= 1 ? k0 : -1;
+                k[2 * r + 1] = nv[r] >= 2 ? k1 : -1;
+                em |= ((nv[r] >= 1 && e0) ? 1u : 0u) << (2 * r) | ((nv[r] >= 2 && e1) ? 1u : 0u) << (2 * r + 1);
+            }
         }
-        }
-        if (redo) {                              // a pixel near a bin / direction edge: the reference's own arithmetic
+        redo = em != 0;
+        if (redo) {
+            // a pixel near a bin / direction edge (about 4 in 10 000, i.e. one in every fifth wave-item): the reference's
+            // own arithmetic, for the flagged pixels alone -- a position no lane has flagged is skipped by the whole wave
 #pragma unroll
             for (int r = 0; r < NR; r++) {
-                if (nv[r] >= 1) k[2 * r] = rc_hist_key(make_float2(v[r].x, v[r].y));
-                if (nv[r] >= 2) k[2 * r + 1] = rc_hist_key(make_float2(v[r].z, v[r].w));
+                if (em >> (2 * r) & 1u) k[2 * r] = rc_hist_key(make_float2(v[r].x, v[r].y));
+                if (em >> (2 * r + 1) & 1u) k[2 * r + 1] = rc_hist_key(make_float2(v[r].z, v[r].w));
             }
         }
 #if RC_HIST_ABL == 1     // timing-only build: loads and keys, no aggregation
