@@ -197,7 +197,7 @@ __device__ __forceinline__ int rc_hist_key_fast(float2 f, bool& exact_needed) {
     const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
     const float ax = fabsf(f.x), ay = fabsf(f.y);
     const bool xmajor = ax >= ay;
-    const float lo = __builtin_fminf(ax, ay), hi = __builtin_fmaxf(ax, ay);
+    const float lo = xmajor ? ay : ax, hi = xmajor ? ax : ay;        // (selects: fminf / fmaxf add a canonicalising v_max each)
     const float c = lo * __builtin_amdgcn_rcpf(hi + (float)DBL_EPSILON);
     const float c2 = c * c;
     float a = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(p7, c2, p5), c2, p3), c2, p1) * c;
@@ -210,11 +210,11 @@ __device__ __forceinline__ int rc_hist_key_fast(float2 f, bool& exact_needed) {
     const float gt = fabsf(__builtin_amdgcn_fractf(t) - 0.5f), gu = fabsf(__builtin_amdgcn_fractf(u) - 0.5f);
     const bool mag_ok = gt < 0.4999f;
     const bool dir_ok = gu < 0.4999f;
-    const int bin = __float2int_rz(t);                               // saturating conversion; t >= 0 or NaN (-> 0, flagged)
+    const int bin = (int)t;                                          // v_cvt_i32_f32 saturates; t >= 0 or NaN (-> 0, flagged)
     const bool counted = bin < RC_HIST_BINS;
     exact_needed = !mag_ok || (counted && !dir_ok);
     // (int)u < 36 wherever dir_ok holds: u = 36 needs a >= 359.99999, whose fractional part fails the guard
-    const int d = __float2int_rz(u);
+    const int d = (int)u;
     return counted ? (int)__umul24((unsigned)d, (unsigned)RC_HIST_BINS) + bin : -1;
 }
 
@@ -241,14 +241,12 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist_rows(const float* flow0
     int gg = i0 / w2, xx = i0 - gg * w2;        // (row group, pair in row), advanced by span per round
     const int dg = span / w2, dx = span - dg * w2;
     const int lane = threadIdx.x & 63;
-    float4 vn[NR];
-    int nn[NR];
     // PLAIN: one 32-bit offset per item and a scalar base per row -- four loads and a handful of address instructions
     // where the general form spends ~120 on bounds, alignment and 64-bit row addresses.  A template parameter, not a
     // run-time flag: with both forms in one loop the number of loads in flight at the keys depends on the path taken
     // and the compiler waits for all of them (vmcnt(0)), i.e. for the prefetch it has just issued.
     constexpr bool plain = PLAIN;
-    auto load_item = [&](int it) {
+    auto load_item = [&](int it, float4 (&vn)[NR], int (&nn)[NR]) {
         const int g = gg, x = xx * 2;
         gg += dg; xx += dx;
         if (xx >= w2) { xx -= w2; gg++; }
@@ -288,13 +286,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist_rows(const float* flow0
             }
         }
     };
-    load_item(0);
-    for (int it = 0; it < rounds; it++) {        // block-uniform trip count: the wave steps below see whole waves
-        float4 v[NR];
-        int nv[NR];
-#pragma unroll
-        for (int r = 0; r < NR; r++) { v[r] = vn[r]; nv[r] = nn[r]; }
-        if (plain || it + 1 < rounds) load_item(it + 1);     // (plain: past the last round the loads are the dummy ones)
+    auto process = [&](const float4 (&v)[NR], const int (&nv)[NR]) {
         int k[2 * NR];
         bool redo = false;
 #if RC_HIST_ABL == 2     // timing-only build: the loads alone
@@ -303,7 +295,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist_rows(const float* flow0
 #pragma unroll
             for (int r = 0; r < NR; r++) acc += v[r].x + v[r].y + v[r].z + v[r].w;
             if (acc == 12345.678f) atomicAdd(&lh[0], 1);
-            continue;
+            return;
         }
 #endif
         unsigned em = 0;                         // bit i: key i has to be taken again with the reference's own arithmetic
@@ -347,7 +339,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist_rows(const float* flow0
 #pragma unroll
             for (int i = 0; i < 2 * NR; i++) acc ^= k[i];
             if (acc == 0x12345678) atomicAdd(&lh[0], 1);
-            continue;
+            return;
         }
 #endif
         // lane level: the first key and its multiplicity; other keys singly
@@ -367,6 +359,19 @@ __global__ __launch_bounds__(RC_BLOCK) void k_polar_hist_rows(const float* flow0
             const int sum = rc_wave_sum(same ? cnt : 0);
             if (lane == leader) atomicAdd(&lh[kL], sum);
             else if (A >= 0 && !same) atomicAdd(&lh[A], cnt);
+        }
+    };
+    // Two register sets, filled in turn one item ahead (no copy at the loop's end: a copy of registers that loads are
+    // still writing would have to wait for those loads).  Block-uniform trip count: the wave-level steps see whole waves.
+    float4 va[NR], vb[NR];
+    int na[NR], nb[NR];
+    load_item(0, va, na);
+    for (int it = 0; it < rounds; it += 2) {
+        if (plain || it + 1 < rounds) load_item(it + 1, vb, nb);     // (plain: past the last round the loads are dummies)
+        process(va, na);
+        if (it + 1 < rounds) {
+            if (plain || it + 2 < rounds) load_item(it + 2, va, na);
+            process(vb, nb);
         }
     }
     __syncthreads();
