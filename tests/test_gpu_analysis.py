@@ -239,6 +239,46 @@ def test_histogram_random_directions(ctx, orc):
     assert np.array_equal(st.hist2d, ost.hist2d) and np.array_equal(st.UPPER2d, ost.UPPER2d)
 
 
+@pytest.mark.parametrize("form", ["plain", "odd_width", "ragged_height", "unaligned_base", "unaligned_pitch"])
+def test_histogram_plain_and_general_forms(ctx, orc, form):
+    """The histogram kernel has a plain form (even width, height a multiple of its four-row items, 16-byte aligned rows: one
+    offset per item, loads issued unconditionally) and a general one; both count what the oracle counts, hazards included
+    (NaN / infinite vectors, exact zeros, magnitudes beyond the last bin, vectors on bin and direction edges)."""
+    w, h = {"plain": (640, 480), "odd_width": (639, 480), "ragged_height": (640, 478),
+            "unaligned_base": (638, 480), "unaligned_pitch": (640, 480)}[form]
+    rng = np.random.RandomState(11)
+    f = _flow_field(w, h, 7, scale=1.7)
+    f[20, 5:60] = (np.nan, 0.3)
+    f[21, 5:60] = (np.inf, -np.inf)
+    f[22, 5:60] = (-np.inf, 0.0)
+    f[23, 5:60, 0] = np.arange(55, dtype=np.float32) * 0.05         # magnitudes on the bin edges, direction 0 exactly
+    f[23, 5:60, 1] = 0.0
+    ang = np.deg2rad(np.arange(55, dtype=np.float32) * 10.0)         # directions on the 10-degree edges
+    f[24, 5:60, 0] = 1.234 * np.cos(ang); f[24, 5:60, 1] = 1.234 * np.sin(ang)
+    f[h - 1, :] = (rng.rand(w, 2).astype(np.float32) - 0.5) * 6      # the last row (of a partial item when the height is ragged)
+    if form == "unaligned_base":
+        big = torch.zeros((h, w + 2, 2), dtype=torch.float32, device="cuda")
+        big[:, 1:w + 1] = torch.as_tensor(f).cuda()
+        dev = big[:, 1:w + 1]                                         # rows start 8 bytes off a 16-byte boundary
+        assert dev.data_ptr() % 16 == 8
+    elif form == "unaligned_pitch":
+        big = torch.zeros((h, w + 1, 2), dtype=torch.float32, device="cuda")
+        big[:, :w] = torch.as_tensor(f).cuda()
+        dev = big[:, :w]                                              # pitch 8 (w + 1) bytes: every other row unaligned
+        assert (dev.stride(0) * 4) % 16 == 8
+    else:
+        dev = torch.as_tensor(f).cuda()
+    st, ost = HistState(), orc.HistState()
+    ctx.analysis_reset(w, h)
+    ctx.create_histogram(dev, st)
+    orc.create_histogram(orc.flow_to_polar(f), ost)
+    assert np.array_equal(st.hist, ost.hist)
+    assert np.array_equal(st.hist2d, ost.hist2d)
+    assert st.histsum == ost.histsum.value
+    assert np.array_equal(st.histsum2d, ost.histsum2d)
+    assert st.UPPER == ost.UPPER and np.array_equal(st.UPPER2d, ost.UPPER2d)
+
+
 def test_classify_accumulate_exact(ctx, orc):
     w, h = 320, 240
     ctx.analysis_reset(w, h)
