@@ -72,6 +72,33 @@ def pmc_traffic(kernel, args):
         return None, None, None
 
 
+SQ_FILE = "profiles/r03_sq_counters.json"
+
+
+def valu_issue(kernel, avg_us, args):
+    """What the dominant kernel's time follows: its vector-instruction count against the SIMDs' issue
+    rate.  Instruction and cycle counts come from the committed SQ counter passes (SQ_FILE, scripts/r3/sq_json.py; counters
+    cannot be collected inside this process), the duration is this run's.  None when the launch shape differs or the file
+    is absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, SQ_FILE)))
+        chunk = args.chunk or 32
+        if min(chunk, args.pairs) != d["pairs_per_launch"] or args.gaussian or args.exact:
+            return None
+        k = d["kernels"][kernel]
+        return {"vector_insts_per_launch": k["insts_valu"], "waves": k["waves"],
+                "cycles_per_inst_per_simd": k["cycles_per_valu_inst_per_simd"],
+                "ns_per_inst_per_simd_this_run": round(avg_us * 1e3 * d["simds"] / k["insts_valu"], 3),
+                "valu_active_share_of_launch": k["valu_active_share_of_launch"],
+                "device_rates_cycles_per_inst": {"pure stream of simple fp32 / integer ops": "2.0 (2.3-2.6 measured at the nominal clock)",
+                                                  "every other or mixed stream": "4.0 (4.4-4.9 measured)"},
+                "source": "%s (commit %s), profiles/r03_valu_rates.md" % (SQ_FILE, d.get("commit", "?")),
+                "note": "the kernel issues one vector instruction per ~4 cycles on every SIMD for the whole launch: "
+                        "bound by instruction issue, not by HBM"}
+    except Exception:
+        return None
+
+
 def measured_memory_roof():
     """Streaming read / write / copy rates of this device from scripts/diag/membw (a stand-alone HIP microbenchmark
     built by __graft_entry__.build(), run as a child process after the timed region; 2 GiB buffers, beyond the
@@ -496,6 +523,9 @@ def main():
                                                            "note": "SURVEY 8(d) bytes of the stages this launch replaces; "
                                                                    "exceeds the peak because those bytes are never moved"},
                                "share_of_gpu_time": round(dom["total_ms"] / tot, 3)}
+            vi = valu_issue(dom["kernel"], 1e3 * dom["total_ms"] / dom["launches"], args)
+            if vi:
+                out["roofline"]["valu_issue"] = vi
             # whole step: compulsory bytes of every launch of a sampled step / wall time of a step
             step_bytes = sum(p["alg_bytes"] for p in prof) / sampled_steps
             out["pipeline"] = {"compulsory_bytes_per_step": step_bytes,

@@ -2,7 +2,7 @@
 # Round-3 profile set, run on the GPU box from the repo root:  bash scripts/r3/profile_round.sh <commit>
 #   1. bench.py with the driver's arguments                      -> gpurun_out/r03_bench.json
 #   2. rocprofv3 --kernel-trace --stats of the same command      -> gpurun_out/r03_bench_kernel_summary.md (+ the stats csv)
-#   3. FETCH_SIZE / WRITE_SIZE passes (one counter per pass)     -> gpurun_out/r03_pmc_traffic.json; SQ passes -> gpurun_out/r03_sq_all.md
+#   3. FETCH_SIZE / WRITE_SIZE passes (one counter per pass)     -> gpurun_out/r03_pmc_traffic.json; SQ passes -> gpurun_out/r03_sq_all.md, r03_sq_counters.json
 #   4. the other BASELINE.md rows (c1, c3, c5, frame, host, host-stateless, gaussian, exact) -> gpurun_out/r03_bench_<row>.json
 #   5. rocprofv3 kernel summary of C3 (4K, five scales)          -> gpurun_out/r03_c3_kernel_summary.md
 commit=${1:-unknown}
@@ -19,6 +19,7 @@ PMC_PASSES=scripts/pmc_passes_traffic.txt PMC_TIMEOUT=300 bash scripts/pmc_multi
 python3 scripts/pmc_traffic_json.py gpurun_out/pmc_r03t_1.txt gpurun_out/pmc_r03t_2.txt 96 32 $commit gpurun_out/r03_pmc_traffic.json
 PMC_PASSES=scripts/r3/pmc_sq2.txt PMC_TIMEOUT=300 bash scripts/pmc_multi.sh r03s --steps 2 --warmup 1 --warmup-seconds 0 --repeats 1 --pairs 32 --no-roof
 python3 scripts/r3/sq_summary.py gpurun_out/pmc_r03s_1.txt gpurun_out/pmc_r03s_2.txt > gpurun_out/r03_sq_all.md
+python3 scripts/r3/sq_json.py gpurun_out/pmc_r03s_1.txt gpurun_out/pmc_r03s_2.txt 32 $commit gpurun_out/r03_sq_counters.json
 echo "pmc done"
 for row in "c1:--config c1" "c3:--config c3" "c5:--config c5" "frame:--mode frame" "host:--mode host" "host_stateless:--mode host-stateless --steps 5 --repeats 3" "gaussian:--gaussian" "exact:--exact --repeats 5"; do
   name=${row%%:*}; args=${row#*:}

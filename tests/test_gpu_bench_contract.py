@@ -34,6 +34,10 @@ def test_bench_prints_one_contract_line():
     assert 0.0 < r["frac"] < 1.0 and r["peak_measured"]["read"] > 1000
     assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9) / r["achieved"] < 0.01
     assert "traffic_source" in r and (r["traffic"] is None or r["traffic_source"])
+    # the issue-rate evidence next to the byte roofline: present only for the launch shape the counters were taken on
+    # (32 pairs per launch), then with a duration-derived figure of this run
+    if "valu_issue" in r:
+        assert r["valu_issue"]["vector_insts_per_launch"] > 0 and r["valu_issue"]["ns_per_inst_per_simd_this_run"] > 0
     assert 0.0 < j["pipeline"]["frac"] < 1.0 and all(0.0 < k["frac"] < 1.0 for k in j["kernels"])
     assert j["warmup_steps_run"] >= 1
     # the headline is the median of `repeats` timed windows of exactly `steps` steps each
