@@ -185,6 +185,24 @@ V.append(("select: one v_cmp vcc then 7 v_cndmask vcc", ["v_cmp_lt_f32 vcc, v16,
 V.append(("select: v_cndmask vcc between fmas (FCFC)", ["v_fma_f32 v16, v16, v41, v42", "v_cndmask_b32 v20, v20, v42, vcc", "v_fma_f32 v24, v24, v41, v42", "v_cndmask_b32 v28, v28, v42, vcc",
            "v_fma_f32 v32, v32, v41, v42", "v_cndmask_b32 v36, v36, v42, vcc", "v_fma_f32 v48, v48, v41, v42", "v_cndmask_b32 v52, v52, v42, vcc"]))
 
+# ---- cross-wave mix: the waves of a SIMD run two different loops (threads 0-255 / 512-767 of a 1024-thread block, i.e. every
+# other wave of each SIMD, loop A; the rest loop B)
+XW = []
+F8 = ["v_fma_f32 v16, v16, v41, v42", "v_fma_f32 v20, v20, v41, v42", "v_fma_f32 v24, v24, v41, v42", "v_fma_f32 v28, v28, v41, v42",
+      "v_fma_f32 v32, v32, v41, v42", "v_fma_f32 v36, v36, v41, v42", "v_fma_f32 v48, v48, v41, v42", "v_fma_f32 v52, v52, v41, v42"]
+H8 = ["v_mul_u32_u24 v16, v16, v41", "v_mul_u32_u24 v20, v20, v41", "v_mul_u32_u24 v24, v24, v41", "v_mul_u32_u24 v28, v28, v41",
+      "v_mul_u32_u24 v32, v32, v41", "v_mul_u32_u24 v36, v36, v41", "v_mul_u32_u24 v48, v48, v41", "v_mul_u32_u24 v52, v52, v41"]
+XW.append(("cross-wave: half of a SIMD's waves all-F (fma), the other half all-H (mul_u24); per instruction of either kind", F8, H8))
+XW.append(("cross-wave control: both halves all-F", F8, F8))
+XW.append(("cross-wave control: both halves all-H", H8, H8))
+# ---- code size: the same all-F stream as one loop body of 32 .. 8192 instructions (is the one-pass rate an artefact of a loop
+# that lives in the instruction buffer?), as VOP3 v_fma_f32 and as VOP2 v_fmac_f32
+LONG = []
+FM8 = ["v_fmac_f32 v%d, v43, v41" % d for d in (16, 20, 24, 28, 32, 36, 48, 52)]
+for reps in (4, 32, 128, 512, 1024):
+    LONG.append(("straight-line all-F stream, loop body %d instructions (%d KB of VOP3)" % (8 * reps, 8 * reps * 8 // 1024), F8, reps))
+    LONG.append(("straight-line all-F stream as VOP2 (v_fmac_f32), loop body %d instructions (%d KB)" % (8 * reps, 8 * reps * 4 // 1024), FM8, reps))
+
 clob = ", ".join('"v%d"' % i for i in range(16, 56)) + ', "s4", "s8", "s9", "s10", "s11", "vcc", "scc"'
 print("// GENERATED by gen_valurate2.py -- do not edit.  See that script for what this measures.")
 print("#include <hip/hip_runtime.h>\n#include <cstdio>\n#include <cstdlib>\n#include <cstring>")
@@ -200,10 +218,34 @@ for k, (name, ins) in enumerate(V):
     print("    }")
     print("    long long t1 = __builtin_readcyclecounter();")
     print("    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;\n}")
+for k, (name, insA, insB) in enumerate(XW):
+    print("__global__ __launch_bounds__(1024) void kx%d(int iters, long long* cyc) {" % k)
+    print('    asm volatile("%s" ::: %s);' % (init, clob))
+    print("    if (((threadIdx.x >> 8) & 1) == 0) {")
+    print("        for (int it = 0; it < iters; it++) {")
+    print('            asm volatile("%s" ::: %s);' % ("\\n\\t".join(insA * 4), clob))
+    print("        }")
+    print("    } else {")
+    print("        for (int it = 0; it < iters; it++) {")
+    print('            asm volatile("%s" ::: %s);' % ("\\n\\t".join(insB * 4), clob))
+    print("        }")
+    print("    }")
+    print("    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = 0;\n}")
+for k, (name, ins, reps) in enumerate(LONG):
+    print("__global__ __launch_bounds__(1024) void kl%d(int iters, long long* cyc) {" % k)
+    print('    asm volatile("%s" ::: %s);' % (init, clob))
+    print("    for (int it = 0; it < iters * 4 / %d; it++) {" % reps)
+    print('        asm volatile("%s" ::: %s);' % ("\\n\\t".join(ins * reps), clob))
+    print("    }")
+    print("    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = 0;\n}")
 print("typedef void (*kern_t)(int, long long*);")
 print("static const struct { const char* name; kern_t k; } VAR[] = {")
 for k, (name, ins) in enumerate(V):
     print('    {"%s", k%d},' % (name, k))
+for k, (name, insA, insB) in enumerate(XW):
+    print('    {"%s", kx%d},' % (name, k))
+for k, (name, ins, reps) in enumerate(LONG):
+    print('    {"%s", kl%d},' % (name, k))
 print("};")
 print(r'''
 int main(int argc, char** argv) {
