@@ -399,7 +399,61 @@ static void launch_pyr_rows(const RcPyrArgs& a, int frames, hipStream_t s) {
     hipLaunchKernelGGL(k_pyr_rows<R>, grid, dim3(RC_BLOCK), lds, s, a);
 }
 
+// Scale 0 on its own (the exact path; the fast path blurs inside the expansion): convertTo + GaussianBlur with the fixed taps
+// (1/4, 1/2, 1/4) of sigma <= 0 + an identity resize = S / 16 with S the nine bytes weighted (1 2 1; 2 4 2; 1 2 1) under
+// BORDER_REFLECT_101 -- smooth.cpp's float row filter then column filter is exact on 8-bit input (every intermediate is a multiple
+// of 1/16 below 256) and the resize at scale 1 multiplies by 1 and adds 0 times a finite neighbour.  A thread owns four pixels
+// of a row: three aligned dwords per source row away from the borders, reflected bytes at them.
+__global__ __launch_bounds__(RC_BLOCK) void k_pyr0_blur3(RcPyrArgs a) {
+    const int W = a.W0, H = a.H0, z = blockIdx.z;
+    const int x = 4 * ((int)blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const uint8_t* src = a.src + (size_t)z * a.src_frame_stride;
+    const bool aligned = ((((size_t)a.src) | a.src_step | a.src_frame_stride) & 3) == 0;
+    const bool fast = aligned && x >= 4 && x + 8 <= W;
+    unsigned int A = 0, B = 0, C = 0, D = 0;     // 16-bit pairs (X0, X2) (X1, X3) (X2, X4) (X3, X5) summed over the rows, X0 = column x - 1
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const uint8_t* row = src + (size_t)rc_reflect101(y - 1 + t, H) * a.src_step;
+        unsigned int pa, pb, pc, pd;
+        if (fast) {
+            const unsigned int* r = (const unsigned int*)(row + x - 4);
+            const unsigned int d0 = r[0], d1 = r[1], d2 = r[2];
+            pa = __builtin_amdgcn_perm(d0, d1, 0x0c010c07u);
+            pb = __builtin_amdgcn_perm(d1, d1, 0x0c020c00u);
+            pc = __builtin_amdgcn_perm(d1, d1, 0x0c030c01u);
+            pd = __builtin_amdgcn_perm(d2, d1, 0x0c040c02u);
+        } else {
+            unsigned int X[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) X[j] = row[rc_reflect101(min(x - 1 + j, W), W)];      // (columns past the row are not stored)
+            pa = X[0] | X[2] << 16; pb = X[1] | X[3] << 16; pc = X[2] | X[4] << 16; pd = X[3] | X[5] << 16;
+        }
+        const int sh = t == 1 ? 1 : 0;
+        A += pa << sh; B += pb << sh; C += pc << sh; D += pd << sh;
+    }
+    const unsigned int o02 = A + 2 * B + C, o13 = B + 2 * C + D;
+    float4 o;
+    o.x = (float)(o02 & 0xffffu) * 0.0625f;
+    o.y = (float)(o13 & 0xffffu) * 0.0625f;
+    o.z = (float)(o02 >> 16) * 0.0625f;
+    o.w = (float)(o13 >> 16) * 0.0625f;
+    const int slot = (a.dslot0 + z * a.zstep) % a.nslots;
+    float* d = a.dst + (size_t)slot * a.dst_slot_stride + (size_t)y * W + x;
+    if (x + 4 <= W && ((W & 3) == 0) && ((((size_t)a.dst) | (a.dst_slot_stride * 4)) & 15) == 0) *(float4*)d = o;
+    else {
+        d[0] = o.x;
+        if (x + 1 < W) d[1] = o.y;
+        if (x + 2 < W) d[2] = o.z;
+        if (x + 3 < W) d[3] = o.w;
+    }
+}
+
 void rc_launch_pyr(const RcPyrArgs& a, int frames, size_t lds, hipStream_t s) {
+    if (a.fixed3 && !a.direct) {
+        hipLaunchKernelGGL(k_pyr0_blur3, dim3((a.W0 + 255) / 256, (a.H0 + 3) / 4, frames), dim3(RC_BLOCK), 0, s, a);
+        return;
+    }
     const size_t rows_lds = ((size_t)ceil(8 * a.scale_y) + a.ksize + 3) * 32 * sizeof(float2);
     if (!a.direct && rows_lds <= 64 * 1024) {
         switch (a.ksize) {

@@ -66,6 +66,7 @@ struct RcPyrArgs {
     const float* kern;        // device, ksize floats
     int tw, th, reg_wp, reg_hmax;
     int direct;               // diagnostic (RC_ABL_PYR_STAGED): the earlier per-pixel / LDS-staged kernels
+    int fixed3;               // scale 0: the fixed (1/4, 1/2, 1/4) taps of sigma <= 0 and an identity resize
 };
 
 // A pyramid scale written by the scale-0 expansion itself (k_polyexp<..., PYR = 1>)

@@ -649,6 +649,7 @@ static int expand_frames(rc_ctx* ctx, RcSlot& s, const uint8_t* d_src, size_t fr
         p.ksize = L.ksize; p.kern = (const float*)s.kern.p + pl.kern_off[k];
         p.tw = L.pyr_tw; p.th = L.pyr_th; p.reg_wp = L.pyr_reg_w; p.reg_hmax = L.pyr_reg_h;
         p.direct = (ctx->ablate & RC_ABL_PYR_STAGED) != 0;
+        p.fixed3 = k == 0 && L.ksize == 3 && !(L.sigma > 0) && L.w == pl.w && L.h == pl.h;
     }
     auto npx = [&](int k) { return (double)pl.lv[k].w * pl.lv[k].h; };
     if (pl.exact) {
@@ -1499,6 +1500,7 @@ extern "C" int rcflow_stage_pyr_level_dev(rc_ctx* ctx, int stream, const uint8_t
     pa.ksize = L.ksize; pa.kern = (const float*)s->stage_f32[0].p;
     pa.tw = L.pyr_tw; pa.th = L.pyr_th; pa.reg_wp = L.pyr_reg_w; pa.reg_hmax = L.pyr_reg_h;
     pa.direct = (ctx->ablate & RC_ABL_PYR_STAGED) != 0;
+    pa.fixed3 = k == 0 && L.ksize == 3 && !(L.sigma > 0) && L.w == w && L.h == h;
     rc_launch_pyr(pa, 1, L.pyr_lds, s->cur);
     RC_HIP(hipGetLastError());
     return RC_OK;

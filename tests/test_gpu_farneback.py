@@ -50,7 +50,8 @@ def _report(name, got, ref):
 
 @pytest.mark.parametrize("size,k", [((640, 480), 0), ((640, 480), 1), ((640, 480), 2), ((333, 251), 1),
                                     ((1920, 1080), 2), ((97, 65), 0), ((1920, 1080), 3), ((1920, 1080), 4),
-                                    ((3840, 2160), 4), ((1000, 700), 3), ((333, 251), 2), ((2001, 1127), 1)])
+                                    ((3840, 2160), 4), ((1000, 700), 3), ((333, 251), 2), ((2001, 1127), 1),
+                                    ((1920, 1080), 0), ((333, 251), 0), ((2001, 1127), 0), ((6, 5), 0)])
 def test_pyr_level_bit_exact(ctx, orc, size, k):
     w, h = size
     img = synth.surf_clip(w, h, 1, seed=7)[0]
